@@ -1,0 +1,151 @@
+/*
+ * rdx.h -- C ABI of the MI355X-native ray-tracing core ("librdx.so").
+ *
+ * This is the drop-in boundary for the hot path  raygen -> BVH traversal -> triangle
+ * intersection -> closest-hit / any-hit / miss -> accumulate  of zekailin00/Radiance-Ray-Tracing.
+ * Every entry point replaces one function of the reference's host runtime
+ * (radiance/include/radiance.h, implemented over OpenCL in radiance/src/radiance.cpp); the
+ * reference interface it stands in for is cited per function.  Plain pointers, sizes and POD
+ * structs only -- no C++ types, no torch types.  The C++ facade `namespace RD` in
+ * include/radiance.h is a thin inline layer over these calls, so reference callers
+ * (samples/sample1.cpp, tools/sceneBuilder.cpp) compile against it unchanged.
+ *
+ * Conventions
+ *   - every function that can fail returns int: 0 = OK, <0 = error (rdx_last_error() has text);
+ *     constructors return a handle or NULL.  The reference never returns errors (it prints and
+ *     exit(-1)s, radiance/src/clcontext.h:27-47); the RD:: facade reproduces that policy on top.
+ *   - single caller thread, blocking calls (radiance.cpp:190-223 use CL_TRUE everywhere).
+ *   - handles stay valid until rdx_shutdown(); nothing needs to be destroyed
+ *     (the reference has no Destroy/Release calls at all, radiance.h:88-144).
+ */
+#ifndef RDX_H
+#define RDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rdx_buffer_s* rdx_buffer;   /* replaces RD::Buffer/Image/TopAccelStruct = cl_mem   (radiance.h:12-19) */
+typedef struct rdx_blas_s*   rdx_blas;     /* replaces RD::BottomAccelStruct                     (radiance.h:52-60) */
+typedef struct rdx_shader_s* rdx_shader;   /* replaces RD::ShaderModule = cl_kernel              (radiance.h:79)    */
+
+/* Host instance record, mirrors RD::Instance (radiance.h:67-74). */
+typedef struct rdx_instance {
+    float    transform[16];      /* row-major object->world (aiMatrix4x4 a1..d4) */
+    uint32_t SBTOffset;
+    uint32_t customInstanceID;
+    rdx_blas bottomAccelStruct;
+} rdx_instance;
+
+/* ---- platform: replaces RD::Platform::GetPlatform / CLContext::GetCLContext
+ *      (radiance.h:146-174, radiance/src/clcontext.cpp:12-40) */
+int         rdx_init(int device_ordinal);            /* idempotent; -1 = current device */
+int         rdx_shutdown(void);
+const char* rdx_last_error(void);
+int         rdx_device_name(char* out, size_t cap);
+
+/* ---- resources: replaces CreateBuffer / CreateImage / ReadBuffer / WriteBuffer
+ *      (radiance.h:115-128, radiance.cpp:86-93,139-146,190-204) */
+rdx_buffer  rdx_buffer_create(size_t size);
+rdx_buffer  rdx_buffer_wrap(void* device_ptr, size_t size);   /* adopt caller-owned device memory (e.g. a torch tensor) */
+int         rdx_buffer_write(rdx_buffer b, size_t offset, size_t size, const void* src);
+int         rdx_buffer_read(rdx_buffer b, size_t offset, size_t size, void* dst);
+void*       rdx_buffer_device_ptr(rdx_buffer b);
+size_t      rdx_buffer_size(rdx_buffer b);
+
+/* ---- acceleration structures: replaces both RD::BuildAccelStruct overloads,
+ *      TopAccelStructToFile and FileToTopAccelStruct
+ *      (radiance.h:88-92, radiance.cpp:20-84,318-479, radiance/src/bvh.cpp:46-597).
+ *      The blobs are byte-identical to the reference's (layout: radiance/shader/data.cl:237-278). */
+rdx_blas    rdx_blas_build(const float* vertices_xyz, uint32_t nvertices,
+                           const uint32_t* indices, uint32_t ntriangles);
+const void* rdx_blas_data(rdx_blas b, uint32_t* size_out);
+int         rdx_blas_max_depth(rdx_blas b);
+rdx_buffer  rdx_tlas_build(const rdx_instance* instances, uint32_t ninstances);
+/* host-only variant: returns the malloc'ed TLAS blob (release with rdx_free); needs no GPU */
+void*       rdx_tlas_build_blob(const rdx_instance* instances, uint32_t ninstances, uint32_t* size_out,
+                                int* max_depth_out);
+void        rdx_free(void* p);
+int         rdx_tlas_to_file(rdx_buffer tlas, const char* path);
+rdx_buffer  rdx_tlas_from_file(const char* path);
+
+/* ---- pipeline: replaces CreateShaderModule / BindPipeline / BindDescriptorSet / TraceRays
+ *      (radiance.h:130-144, radiance.cpp:152-179,226-267).
+ *      `code` is the user's shader text; the stage functions named in samples/sbt.json
+ *      (raygen, material, shadow, anyShadow, environment, shadowMiss) are resolved against the
+ *      hand-written HIP stages compiled into this library (tools/genSBT.py emits the dispatch).
+ *      A shader that names no `raygen` kernel fails here, as clCreateKernel("raygen") would. */
+rdx_shader  rdx_shader_module_create(const char* code, uint32_t size, const char* name);
+int         rdx_bind_pipeline(rdx_shader raygen_module);
+/* handles[i] binds to parameter i of the raygen kernel (samples/shader.cl:175-190):
+ * 0 RTProp, 1 imageScratch, 2 image, 3 camData, 4 scene, 5 meshInfo, 6 vertex, 7 index, 8 uv,
+ * 9 normal, 10 material, 11 textureArray (may be NULL), 12 sampler (may be NULL), 13 TLAS. */
+int         rdx_bind_descriptor_set(void* const* handles, uint32_t n);
+/* the three SBT indices are accepted and ignored, exactly like radiance.cpp:242-259 */
+int         rdx_trace_rays(uint32_t raygenGroupIndex, uint32_t missGroupIndex, uint32_t hitGroupIndex,
+                           uint32_t width, uint32_t height);
+
+/* ---- extensions (no reference counterpart) ------------------------------------------------ */
+
+/* Image-tile sharding for multi-GPU: this process renders only the pixels whose tile id
+ * (row-major over tile_w x tile_h tiles) is congruent to `rank` mod `world`.  Pixel/RNG indices
+ * stay global, so the union over ranks is bit-identical to an unsharded frame. */
+int         rdx_set_shard(uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h);
+/* pack this rank's tiles of a W*H image of `elem_size`-byte pixels into a contiguous buffer
+ * (and the inverse on the gathering rank) */
+int         rdx_pack_tiles(rdx_buffer image, rdx_buffer packed, uint32_t width, uint32_t height,
+                           uint32_t elem_size, uint32_t rank, uint32_t world);
+int         rdx_unpack_tiles(rdx_buffer packed, rdx_buffer image, uint32_t width, uint32_t height,
+                             uint32_t elem_size, uint32_t rank, uint32_t world);
+uint32_t    rdx_shard_pixel_count(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
+
+/* Statistics of the last rdx_trace_rays call. */
+typedef struct rdx_trace_stats {
+    uint64_t rays_primary, rays_bounce, rays_shadow;   /* rays actually traced */
+    uint64_t closest_hits;                             /* `material` invocations */
+    uint64_t pixels;                                   /* pixels rendered by this rank */
+    /* visit counters of the reference algorithm's exhaustive walk, filled only when option
+     * "count_visits" is 1: index 0 = radiance rays, 1 = shadow rays (SURVEY.md 8d byte model) */
+    uint64_t visit_top_nodes[2], visit_instances[2], visit_bot_nodes[2], visit_triangles[2];
+    float    ms_total;                                 /* HIP-event time of the whole call */
+    float    ms_generate, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_sort;
+    uint32_t launches_extend, launches_shadow;
+} rdx_trace_stats;
+int         rdx_get_trace_stats(rdx_trace_stats* out);
+/* 0 = per-stage HIP events off (default), 1 = on (adds launch gaps; for profiling only) */
+int         rdx_set_profiling(int on);
+/* knobs: "chunk_paths" (paths in flight per chunk), "count_visits" (0/1: also count node /
+ * triangle visits; slower, for the roofline byte model) */
+int         rdx_set_option(const char* name, int64_t value);
+
+/* Test seams: run single stages on caller-supplied batches (device or host pointers are NOT
+ * accepted -- plain host arrays in, host arrays out; the library stages them through HBM). */
+typedef struct rdx_hit {
+    float    hitPoint[3];
+    float    distance;
+    uint32_t primitiveIndex, instanceIndex, instanceCustomIndex, instanceSBTOffset;
+    float    barycentric[3];
+    uint32_t hit;
+    float    transform[16];
+} rdx_hit;      /* mirrors struct HitData, radiance/shader/radiance.cl:8-18 (+ the hit flag) */
+/* visit8 (optional): {top_nodes, instances, bot_nodes, triangles} visit counts summed over the batch */
+int         rdx_trace_batch(rdx_buffer tlas, const float* origins_xyz, const float* dirs_xyz, uint32_t n,
+                            float tmin, float tmax, int sbtRecordOffset, rdx_hit* out, uint64_t* visit4);
+typedef struct rdx_payload {
+    float color[3]; uint32_t hit; float nextFactor[3]; float nextRayOrigin[3]; float nextRayDirection[3];
+} rdx_payload;  /* mirrors struct Payload, samples/shader.cl:4-13 */
+/* closest-hit `material` (samples/shader.cl:482-541) on captured hits, using the bound descriptors */
+int         rdx_material_batch(const rdx_hit* hits, const float* ray_dirs_xyz, const uint32_t* pixels,
+                               const uint32_t* frame_ids, const int32_t* depths, uint32_t n, rdx_payload* out);
+/* primary rays (samples/shader.cl:111-173) for explicit pixels / rng inputs, using the bound camera */
+int         rdx_generate_batch(const uint32_t* pixels, const uint32_t* rand_in3, uint32_t n,
+                               float* origins_xyz, float* dirs_xyz);
+int         rdx_pcg3d_batch(const uint32_t* in3, float* out3, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDX_H */

@@ -1,0 +1,159 @@
+/*
+ * rt_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C restatement of the hot path of zekailin00/Radiance-Ray-Tracing:
+ *   host  : binned-SAH BVH builder + BLAS/TLAS blob packers
+ *           (radiance/src/bvh.cpp:46-597, radiance/src/radiance.cpp:318-425)
+ *   device: traceRay / intersectTop / intersectBot / intersectAABB /
+ *           intersectTriangle (radiance/shader/radiance.cl:41-275),
+ *           math + PBR helpers (radiance/shader/math.cl, pbr.cl),
+ *           raygen / generateRay / material / SBT switches (samples/shader.cl).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported baseline.  The product
+ * (radiance-ray-tracing_amd/) never links, imports or calls it.
+ *
+ * PARITY PIN STATUS
+ *   The reference has no tests, golden vectors or fixtures
+ *   and cannot be built here as a whole: its host side needs the assimp
+ *   headers (empty submodule) and its device side needs an OpenCL runtime's
+ *   builtin library (no CPU OpenCL driver in the image).  What IS pinned by
+ *   the real reference: the builtin-free device functions (random_pcg3d,
+ *   InverseMat4x4, MultiplyMat4Vec4, MultiplyMat4Mat4, D_GGX), executed from
+ *   the reference's own samples/shader.cl compiled for x86 by oracle/Makefile
+ *   into oracle/_ref/ (see oracle/ref_harness.c, tests/golden/ref_*.npz), and
+ *   the SBT row mapping produced by the reference's tools/genSBT.py.
+ *   Everything else in this file is "parity unpinned": a restatement by
+ *   reading, with the OpenCL builtins the driver would supply pinned to the
+ *   definitions stated below.
+ *
+ * Floating-point pin (OpenCL leaves these to the driver):
+ *   no fp contraction (-ffp-contract=off), IEEE fp32 + - * / sqrt,
+ *   min(x,y) = y<x ? y : x, max(x,y) = x<y ? y : x,
+ *   clamp(x,lo,hi) = min(max(x,lo),hi), mix(a,b,t) = a + (b-a)*t,
+ *   dot accumulated x->y->z(->w), cross per the OpenCL spec,
+ *   normalize(v) = v / sqrt(dot(v,v)); sin/cos/acos/pow = libm float versions.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- blob layouts (radiance/shader/data.cl:4-83, radiance/src/core.h:34-101) */
+typedef struct { uint32_t type, nodeByteOffset, instByteOffset, totalBufferSize; } OrcAccelTop;
+typedef struct { uint32_t type, nodeByteOffset, faceByteOffset, vertexOffset; }    OrcAccelBot;
+typedef struct { float bottom[4]; float top[4]; uint32_t w0, w1, w2, w3; }          OrcNode;     /* 48 B */
+typedef struct { uint32_t idx0, idx1, idx2, primID; }                               OrcTri;      /* 16 B */
+typedef struct { float r[16]; uint32_t SBTOffset, instanceID, customInstanceID, instanceOffset; } OrcInst; /* 80 B */
+
+/* host-side structs bound to the raygen kernel (radiance/src/core.h:103-158) */
+typedef struct { uint32_t totalSamples, batchSize, depth, debug; } OrcRTProp;
+typedef struct { float albedo[4]; float metallic, roughness, transmission, ior;
+                 int32_t albedoTexIdx, metallicTexIdx, roughnessTexIdx, normalTexIdx; } OrcMaterial;   /* 48 B */
+typedef struct { int32_t vertexOffset, indexOffset, uvOffset, normalOffset, materialIndex, _0, _1, _2; } OrcMeshInfo; /* 32 B */
+typedef struct { float direction[4]; float color[4]; } OrcDirLight;                 /* 32 B */
+typedef struct { uint32_t lightCount[4]; OrcDirLight lights[5]; } OrcSceneProps;    /* 176 B */
+typedef struct { float widthPixel, heightPixel, focalLength, sensorWidth, focalDistance, fStop,
+                 x, y, z, wx, wy, wz; } OrcCamera;                                   /* 48 B */
+
+/* per-ray result, mirrors struct HitData (radiance/shader/radiance.cl:8-18) */
+typedef struct {
+    float    hitPoint[3];
+    float    distance;
+    uint32_t primitiveIndex, instanceIndex, instanceCustomIndex, instanceSBTOffset;
+    float    barycentric[3];
+    uint32_t hit;              /* return value of intersectTop */
+    float    transform[16];
+} OrcHit;
+
+/* visit counters for the algorithmic-bytes model */
+typedef struct {            /* index 0 = radiance rays (sbtRecordOffset 1), 1 = shadow rays (2) */
+    uint64_t rays[2];        /* traceRay invocations */
+    uint64_t top_nodes[2];   /* nodes popped in intersectTop */
+    uint64_t inst_visits[2]; /* instances entered */
+    uint64_t bot_nodes[2];   /* nodes popped in intersectBot */
+    uint64_t tri_tests[2];   /* intersectTriangle calls */
+    uint64_t hits;           /* closest-hit shader invocations (material) */
+    uint64_t primary, bounce, shadow;   /* ray classes as issued by raygen / material */
+} OrcCounters;
+
+/* instance description handed to the TLAS builder (radiance.h:67-74) */
+typedef struct {
+    float    transform[16];     /* row-major object->world */
+    uint32_t SBTOffset;
+    uint32_t customInstanceID;
+    uint32_t blas;              /* index into the blas handle array */
+} OrcInstanceDesc;
+
+/* the 14 descriptor slots of the live pipeline (samples/shader.cl:175-190) */
+typedef struct {
+    OrcRTProp*      RTProp;
+    float*          imageScratch;
+    uint8_t*        image;
+    const OrcCamera*      camData;
+    const OrcSceneProps*  scene;
+    const OrcMeshInfo*    meshInfoData;
+    const float*          vertexData;
+    const uint32_t*       indexData;
+    const float*          uvData;
+    const float*          normalData;
+    const OrcMaterial*    materials;
+    const void*           topLevel;     /* TLAS blob */
+} OrcBindings;
+
+/* ---- builder */
+void*       orc_blas_build(const float* verts_xyz, uint32_t nverts, const uint32_t* tris, uint32_t ntris);
+uint32_t    orc_blas_size(const void* blas);
+const void* orc_blas_data(const void* blas);
+int         orc_blas_max_depth(const void* blas);
+void        orc_blas_free(void* blas);
+/* returns malloc'ed TLAS blob (free with orc_free); size via *out_size */
+void*       orc_tlas_build(const OrcInstanceDesc* inst, uint32_t ninst, void* const* blas_handles,
+                           uint32_t* out_size, int* out_max_depth);
+void        orc_free(void* p);
+
+/* ---- traversal */
+/* sbtRecordOffset: 1 = radiance ray (closest hit), 2 = shadow ray (any-hit terminates) */
+void orc_trace_batch(const void* tlas, const float* origins, const float* dirs, uint32_t n,
+                     float tmin, float tmax, int sbtRecordOffset, OrcHit* out, OrcCounters* ctr);
+
+/* ---- unit entry points (KATs) */
+void  orc_pcg3d(const uint32_t* in3, float* out3, uint32_t n);
+int   orc_inverse_mat4(const float* m16, float* out16);
+void  orc_mul_mat4_vec4(const float* m16, const float* v4, float* out4);
+int   orc_intersect_aabb(const float* o3, const float* d3, const float* bmin3, const float* bmax3);
+int   orc_intersect_triangle(const float* o3, const float* d3, const float* v0, const float* v1,
+                             const float* v2, float* t, float* point3, float* bary3);
+void  orc_generate_ray(const OrcCamera* cam, uint32_t pixel, const uint32_t* rand_in3,
+                       float* origin3, float* dir3);
+void  orc_microfacet_brdf(const float* L, const float* V, const float* N, const float* albedo,
+                          float metallic, float roughness, float transmission, float ior, float* out3);
+void  orc_sample_brdf_transm(const float* V, const float* N, const float* baseColor,
+                             float metallic, float roughness, float transmission, float ior,
+                             const float* random3, float* nextFactor3, float* L3);
+float orc_d_ggx(float dotNH, float roughness);
+void  orc_aces(const float* in3, float* out3);
+
+/* closest-hit `material` on captured hits: payload in = nextRayDirection; out = color, nextFactor,
+   nextRayOrigin, nextRayDirection (shader.cl:482-541). pixel/frameID/depth feed the RNG. */
+typedef struct { float color[3]; uint32_t hit; float nextFactor[3]; float nextRayOrigin[3]; float nextRayDirection[3]; } OrcPayload;
+void  orc_material_batch(const OrcBindings* b, const OrcHit* hits, const float* ray_dirs, const uint32_t* pixels,
+                         const uint32_t* frame_ids, const int32_t* depths, uint32_t n, OrcPayload* out);
+
+/* ---- whole-kernel: runs `raygen` (shader.cl:175-305) for pixels [begin,end) ; nthreads<=0 -> all */
+void  orc_render(const OrcBindings* b, uint32_t pixel_begin, uint32_t pixel_end, int nthreads, OrcCounters* ctr);
+/* same but for an explicit pixel list (tile sharding tests) */
+void  orc_render_pixels(const OrcBindings* b, const uint32_t* pixels, uint32_t n, int nthreads, OrcCounters* ctr);
+
+/* struct size table for the layout KATs */
+void  orc_struct_sizes(uint32_t* out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

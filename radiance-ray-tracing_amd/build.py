@@ -1,0 +1,45 @@
+"""build.py -- compiles the HIP ray-tracing core into radiance-ray-tracing_amd/librdx.so (in-tree).
+
+hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off is part of the numerical
+contract: traversal / intersection results must be the IEEE values of the
+expressions as written.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librdx.so")
+SOURCES = ["kernels.hip", "rdx_runtime.cpp", "bvh_build.cpp"]
+HEADERS = ["kernels.h", "stages.h", "device_math.h", "rdx_types.h", "bvh_build.h", "sbt_generated.h",
+           os.path.join("..", "..", "include", "rdx.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    # regenerate the SBT tables from samples/sbt.json
+    gen = os.path.join(HERE, "..", "tools", "genSBT.py")
+    subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
+    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("built", LIB)

@@ -1,0 +1,81 @@
+// kernels.h -- launch interface between the host runtime (rdx_runtime.cpp) and the HIP stages
+// (kernels.hip).  All pointers are device pointers; all launches go to the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rdx.h"
+#include "rdx_types.h"
+
+namespace rdx {
+
+struct AccelView {                 // derived traversal layout (see rdx_types.h)
+    const DNode* tnodes;
+    const DInst* insts;
+    const DNode* bnodes;
+    const DTri*  tris;
+    uint32_t stackNeed;            // worst-case stack entries of an exhaustive DFS
+};
+
+struct SceneArgs {                 // descriptor slots 4-10 (samples/shader.cl:175-190)
+    const SceneProperties* scene;
+    const MeshInfo* meshInfo;
+    const uint32_t* indexData;
+    const float* uvData;
+    const float* normalData;
+    const Material* materials;
+};
+
+struct CameraArgs {                // slot 3 + per-frame constants hoisted out of generateRay
+    PhysicalCamera cam;
+    float rotX[16], rotY[16], rotZ[16];   // EulerX/Y/ZToMat4x4(cam.wx/wy/wz), math.cl:185-252
+};
+
+// Wavefront path state.  Two sets of float4 streams that ping-pong:
+//   A (one entry per live path at the start of a bounce)
+//   B (one entry per path that hit something, compacted by the shade stage)
+struct PathStreams {
+    float4* rayO;      // A: origin.xyz, w = global pixel index (bits)
+    float4* rayD;      // A: direction.xyz, w = frameID (bits)
+    float4* thr;       // A: contribution.xyz, w = owned-pixel slot (bits)
+    float4* col;       // A: accumulated colour.xyz
+    float4* hitA;      // A: t, b1, b2, primitive slot->primID (bits)
+    uint32_t* hitInst; // A: instance slot or 0xffffffff (miss)
+    float4* shO;       // B: shadow-ray origin.xyz, w = pixel
+    float4* nextO;     // B: next origin.xyz, w = frameID
+    float4* nextD;     // B: next direction.xyz, w = slot
+    float4* thrN;      // B: contribution after this bounce
+    float4* colLit;    // B: colour if the light is visible
+    float4* colSh;     // B: colour if it is occluded
+    float4* sampleColor; // [samples_in_chunk][pixels] final per-sample radiance
+};
+
+void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& ps, const uint32_t* ownedPixels,
+                     uint32_t nPixels, uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples);
+// nPtr: device word holding the live count of this stage; nMax: upper bound used to size the grid
+void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,
+                   float tmin, float tmax, unsigned long long* visit);
+void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
+                  uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase);
+void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
+                   uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,
+                   unsigned long long* visit);
+void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* ownedPixels, uint32_t nPixels,
+                       uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples, bool tonemap, uint32_t debug,
+                       float* imageScratch, uint8_t* image);
+void launch_finalize_all(hipStream_t st, const PathStreams& ps, uint32_t n, uint32_t nPixels, uint32_t sampleBase);
+
+void launch_pack_tiles(hipStream_t st, const uint8_t* image, uint8_t* packed, uint32_t w, uint32_t h, uint32_t elem,
+                       uint32_t tileW, uint32_t tileH, uint32_t rank, uint32_t world, bool unpack);
+
+// test seams
+void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, const float* d, uint32_t n, float tmin,
+                        float tmax, int rec, rdx_hit* out, unsigned long long* visit);
+void launch_material_batch(hipStream_t st, const SceneArgs& sc, const rdx_hit* hits, const float* dirs,
+                           const uint32_t* pixels, const uint32_t* frames, const int32_t* depths, uint32_t n,
+                           rdx_payload* out);
+void launch_generate_batch(hipStream_t st, const CameraArgs& cam, const uint32_t* pixels, const uint32_t* rnd,
+                           uint32_t n, float* o, float* d);
+void launch_pcg3d_batch(hipStream_t st, const uint32_t* in3, float* out3, uint32_t n);
+
+} // namespace rdx

@@ -1,0 +1,632 @@
+// kernels.hip -- wavefront path-tracing stages for MI355X (gfx950, wave64).
+//
+// Stage graph of one bounce (all launches on one HIP stream):
+//
+//   generate ──► [A streams] ──► extend (closest hit, exhaustive BVH walk)
+//                                   │ hit records
+//                                   ▼
+//                                shade  (SBT dispatch: material / environment; wave64 ballot
+//                                   │    compaction of the paths that hit into the B streams)
+//                                   ▼
+//                                shadow (any-hit walk for the deferred shadow query, picks the
+//                                   │    lit / occluded colour, writes the next bounce's A streams)
+//                                   ▼
+//                       ... next bounce ...  ──►  accumulate (running mean, ACES + gamma, RGBA8)
+//
+// Exactness contract of the traversal (see DESIGN.md "Traversal"): the set of nodes a ray visits,
+// the slab test, the Möller–Trumbore arithmetic, the accept test and the visiting order are those of
+// radiance/shader/radiance.cl:41-251; only the data layout and the execution model differ.
+#include "kernels.h"
+#include "stages.h"
+
+#include <cfloat>
+
+namespace rdx {
+
+#define RDX_BLOCK 256
+#define RDX_MISS 0xffffffffu
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// ---------------------------------------------------------------------------------------------
+// traversal
+// ---------------------------------------------------------------------------------------------
+
+// radiance.cl:195-208 -- slab test by division, tFar > max(tNear, 0); no best-t culling
+__device__ __forceinline__ bool slab_hit(f3 o, f3 d, const float4& bmin, const float4& bmax)
+{
+    f3 tA = (mk3(bmin.x, bmin.y, bmin.z) - o) / d;
+    f3 tB = (mk3(bmax.x, bmax.y, bmax.z) - o) / d;
+    f3 t1 = mk3(cl_min(tA.x, tB.x), cl_min(tA.y, tB.y), cl_min(tA.z, tB.z));
+    f3 t2 = mk3(cl_max(tA.x, tB.x), cl_max(tA.y, tB.y), cl_max(tA.z, tB.z));
+    float tNear = cl_max(cl_max(t1.x, t1.y), t1.z);
+    float tFar = cl_min(cl_min(t2.x, t2.y), t2.z);
+    return tFar > cl_max(tNear, 0.0f);
+}
+
+struct TraceResult {
+    float t, b1, b2;
+    uint32_t prim, inst;
+    bool hit;
+    uint32_t nTop, nInst, nBot, nTri;   // visit counts (COUNT builds only; SURVEY.md 8d byte model)
+};
+
+// One ray, one lane.  Left-first DFS with the lane's stack in LDS ([level][lane], conflict-free).
+// REC is the sbtRecordOffset of traceRay(): 1 = radiance ray, 2 = shadow ray.  Whether an accepted
+// candidate terminates the walk is decided by the generated any-hit table (row 2 -> anyShadow).
+template <int REC, bool COUNT>
+__device__ __forceinline__ void traverse(const AccelView& A, f3 o, f3 d, float tmin, float tmax,
+                                         uint32_t* __restrict__ stack, uint32_t stride, TraceResult& r)
+{
+    uint32_t sp = 0;
+    uint32_t cur = TAG_TLAS | 0u;
+    f3 lo = o, ld = d;
+    uint32_t curInst = 0;
+    r.t = FLT_MAX; r.b1 = 0.f; r.b2 = 0.f; r.prim = 0; r.inst = RDX_MISS; r.hit = false;
+    r.nTop = r.nInst = r.nBot = r.nTri = 0;
+
+    for (;;) {
+        const uint32_t tag = cur & TAG_MASK, idx = cur & IDX_MASK;
+        if (tag == TAG_INST) {
+            if (COUNT) ++r.nInst;
+            // enter an instance: object-space ray = inverse(object->world) * (o,1), (d,0)   (radiance.cl:161-169)
+            const float4* ip = reinterpret_cast<const float4*>(A.insts[idx].inv);
+            float m[16];
+            *reinterpret_cast<float4*>(m + 0) = ip[0];
+            *reinterpret_cast<float4*>(m + 4) = ip[1];
+            *reinterpret_cast<float4*>(m + 8) = ip[2];
+            *reinterpret_cast<float4*>(m + 12) = ip[3];
+            lo = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
+            ld = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
+            curInst = idx;
+            cur = A.insts[idx].blasRoot;
+            continue;
+        }
+        const bool top = (tag == TAG_TLAS);
+        if (COUNT) { if (top) ++r.nTop; else ++r.nBot; }
+        const float4* np = reinterpret_cast<const float4*>((top ? A.tnodes : A.bnodes) + idx);
+        const float4 bmin = np[0], bmax = np[1];
+        const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
+        if (!(w.x & LEAF_BIT)) {
+            if (slab_hit(top ? o : lo, top ? d : ld, bmin, bmax)) {
+                stack[sp * stride] = tag | w.y;      // right child waits
+                ++sp;
+                cur = tag | w.x;                     // left child next
+                continue;
+            }
+        } else if (top) {
+            const uint32_t count = w.x & 0x7fffffffu;
+            if (w.z == TYPE_INST && count > 0) {
+                for (uint32_t i = count - 1; i >= 1; --i) { stack[sp * stride] = TAG_INST | (w.y + i); ++sp; }
+                cur = TAG_INST | w.y;
+                continue;
+            }
+        } else if (w.z == TYPE_TRIG) {
+            const uint32_t count = w.x & 0x7fffffffu;
+            for (uint32_t i = 0; i < count; ++i) {
+                if (COUNT) ++r.nTri;
+                const float4* tp = reinterpret_cast<const float4*>(A.tris + (w.y + i));
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                // Möller–Trumbore, radiance.cl:211-251
+                const f3 e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+                const f3 rce2 = cross3(ld, e2);
+                const float det = dot3(e1, rce2);
+                if (det == 0) continue;
+                const float inv_det = 1.0f / det;
+                const f3 s = lo - mk3(q0.x, q0.y, q0.z);
+                const float b1 = inv_det * dot3(s, rce2);
+                const f3 sce1 = cross3(s, e1);
+                const float b2 = inv_det * dot3(ld, sce1);
+                const float t = inv_det * dot3(e2, sce1);
+                if (b1 < 0 || b1 > 1) continue;
+                if (b2 < 0 || b1 + b2 > 1) continue;
+                if (!(t > 0)) continue;
+                if (t < r.t && t > tmin && t < tmax) {           // radiance.cl:90-91
+                    r.t = t; r.b1 = b1; r.b2 = b2; r.prim = f2u(q0.w); r.inst = curInst; r.hit = true;
+                    bool cont = true;
+                    callAnyHit(cont, (int)A.insts[curInst].SBTOffset + REC);
+                    if (!cont) return;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * stride];
+    }
+}
+
+extern __shared__ uint32_t s_stack[];
+
+// COUNT builds: add this lane's visit counts to visit[cls*4 + {top, inst, bot, tri}]
+__device__ __forceinline__ void flush_visits(unsigned long long* visit, int cls, const TraceResult& r)
+{
+    atomicAdd(visit + cls * 4 + 0, (unsigned long long)r.nTop);
+    atomicAdd(visit + cls * 4 + 1, (unsigned long long)r.nInst);
+    atomicAdd(visit + cls * 4 + 2, (unsigned long long)r.nBot);
+    atomicAdd(visit + cls * 4 + 3, (unsigned long long)r.nTri);
+}
+
+// ---------------------------------------------------------------------------------------------
+// generate: primary rays (samples/shader.cl:111-173, 196-231)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void camera_ray(const CameraArgs& C, uint32_t pixel, f3 rnd, f3& org, f3& dir)
+{
+    const PhysicalCamera& cam = C.cam;
+    const int index = (int)pixel;
+    const int x = index % (int)cam.widthPixel;
+    const int y = index / (int)cam.widthPixel;
+    const float fx = (((float)x + rnd.x) / cam.widthPixel) - 0.5f;
+    const float fy = 0.5f - (((float)y + rnd.y) / cam.heightPixel);
+    const float aspect = cam.heightPixel / cam.widthPixel;
+    f4 pd; pd.x = fx * cam.sensorWidth; pd.y = fy * cam.sensorWidth * aspect; pd.z = -cam.focalLength; pd.w = 0.0f;
+    pd = normalize4(pd);
+    const f3 eye = mk3(cam.x, cam.y, cam.z);
+    const float time = -cam.focalDistance / pd.z;
+    f4 t = mat4_mul(C.rotZ, pd.x, pd.y, pd.z, pd.w);
+    pd = mat4_mul(C.rotY, t.x, t.y, t.z, t.w);
+    t = mat4_mul(C.rotX, pd.x, pd.y, pd.z, pd.w);
+    pd = normalize4(t);
+    if (cam.fStop == 0.0f) { org = eye; dir = mk3(pd.x, pd.y, pd.z); return; }
+
+    // thin lens: concentric disk sample from rnd.yz (shader.cl:89-109, 155-172)
+    const float lensRadius = (cam.focalLength / cam.fStop) / 2.0f;
+    float ux = 2.0f * rnd.y - 1.0f, uy = 2.0f * rnd.z - 1.0f;
+    float lx = 0.0f, ly = 0.0f;
+    if (!(ux == 0.0f && uy == 0.0f)) {
+        float theta, rr;
+        if (fabsf(ux) > fabsf(uy)) { rr = ux; theta = (RDX_PI / 4.0f) * (uy / ux); }
+        else { rr = uy; theta = (RDX_PI / 2.0f) - (RDX_PI / 4.0f) * (ux / uy); }
+        lx = rr * cosf(theta); ly = rr * sinf(theta);
+    }
+    lx = lensRadius * lx; ly = lensRadius * ly;
+    const f3 focus = eye + mk3(pd.x, pd.y, pd.z) * time;
+    f4 l = mat4_mul(C.rotZ, lx, ly, 0.0f, 1.0f);
+    f4 l2 = mat4_mul(C.rotY, l.x, l.y, l.z, l.w);
+    l = mat4_mul(C.rotX, l2.x, l2.y, l2.z, l2.w);
+    org = eye + mk3(l.x, l.y, l.z);
+    dir = normalize3(focus - org);
+}
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_generate(CameraArgs C, PathStreams ps, const uint32_t* __restrict__ owned, uint32_t nPixels, uint32_t sampleBegin,
+           uint32_t sampleCount, uint32_t totalSamples)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (i >= nPixels * sampleCount) return;
+    const uint32_t sLocal = i / nPixels, slot = i - sLocal * nPixels;
+    const uint32_t pixel = owned ? owned[slot] : slot;
+    const uint32_t frameID = totalSamples + sampleBegin + sLocal;
+    const f3 rnd = pcg3d(frameID, totalSamples, pixel);      // shader.cl:205
+    f3 o, d;
+    camera_ray(C, pixel, rnd, o, d);
+    ps.rayO[i] = make_float4(o.x, o.y, o.z, u2f(pixel));
+    ps.rayD[i] = make_float4(d.x, d.y, d.z, u2f(frameID));
+    ps.thr[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(slot));
+    ps.col[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// extend: closest hit for every live path
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_extend(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, float tmin, float tmax,
+         unsigned long long* __restrict__ visit)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nPtr) return;
+    const float4 ro = ps.rayO[i], rd = ps.rayD[i];
+    TraceResult r;
+    traverse<1, COUNT>(A, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
+    ps.hitA[i] = make_float4(r.t, r.b1, r.b2, u2f(r.prim));
+    ps.hitInst[i] = r.hit ? r.inst : RDX_MISS;
+    if (COUNT) flush_visits(visit, 0, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: SBT dispatch + ballot compaction
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_sample(const PathStreams& ps, uint32_t nPixels, uint32_t sampleBase,
+                                             uint32_t frameID, uint32_t slot, f3 c)
+{
+    ps.sampleColor[(size_t)(frameID - sampleBase) * nPixels + slot] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
+__device__ __forceinline__ void fill_hit_info(const AccelView& A, uint32_t instSlot, f3 o, f3 d, float t, float b1,
+                                              float b2, uint32_t prim, HitInfo& h)
+{
+    const DInst& I = A.insts[instSlot];
+    // hitPoint = localOrigin + localDir * t, as computed at accept time (radiance.cl:243)
+    const f3 lo = mat4_mul3(I.inv, o.x, o.y, o.z, 1.0f);
+    const f3 ld = mat4_mul3(I.inv, d.x, d.y, d.z, 0.0f);
+    h.hitPoint = lo + ld * t;
+    h.bx = 1 - b1 - b2; h.by = b1; h.bz = b2;
+    h.primitiveIndex = prim;
+    h.instanceIndex = I.instanceID;
+    h.fwd = I.fwd;
+}
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ nOut,
+        uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    const bool active = i < *nPtr;
+    bool alive = false;
+    Payload p;
+    float4 ro, rd, thr, col;
+    if (active) {
+        ro = ps.rayO[i]; rd = ps.rayD[i]; thr = ps.thr[i]; col = ps.col[i];
+        const uint32_t instSlot = ps.hitInst[i];
+        const uint32_t pixel = f2u(ro.w), frameID = f2u(rd.w), slot = f2u(thr.w);
+        p.hit = false; p.wantsShadowRay = false;
+        p.color = mk3(0.f, 0.f, 0.f); p.colorOccluded = p.color;
+        p.nextFactor = mk3(1.f, 1.f, 1.f);
+        p.nextRayOrigin = mk3(ro.x, ro.y, ro.z); p.nextRayDirection = mk3(rd.x, rd.y, rd.z);
+        p.shadowOrigin = p.nextRayOrigin;
+        const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials};
+        if (instSlot != RDX_MISS) {
+            const float4 ha = ps.hitA[i];
+            HitInfo h;
+            fill_hit_info(A, instSlot, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ha.x, ha.y, ha.z, f2u(ha.w), h);
+            callHit((int)A.insts[instSlot].SBTOffset + 1, p, h, sv, mk3(rd.x, rd.y, rd.z), frameID, pixel, depth,
+                    depth + 1 < maxDepth);
+        } else {
+            callMiss(3, p);
+        }
+        if (p.hit) {
+            alive = true;
+        } else {
+            // shader.cl:243-252: a primary miss shows the miss colour, a later miss ends the path
+            f3 c = (depth == 0) ? p.color : mk3(col.x, col.y, col.z);
+            store_sample(ps, nPixels, sampleBase, frameID, slot, c);
+        }
+    }
+    // wave64 ballot compaction of the surviving paths into the B streams
+    const unsigned long long m = __ballot(alive);
+    if (m == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(nOut, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (!alive) return;
+    const uint32_t j = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
+    const f3 lit = Cc + T * p.color;               // color += contribution * payload.color (shader.cl:240)
+    const f3 occ = Cc + T * p.colorOccluded;
+    const f3 tn = T * p.nextFactor;                // contribution *= payload.nextFactor    (shader.cl:241)
+    ps.shO[j] = make_float4(p.shadowOrigin.x, p.shadowOrigin.y, p.shadowOrigin.z, ro.w);
+    ps.nextO[j] = make_float4(p.nextRayOrigin.x, p.nextRayOrigin.y, p.nextRayOrigin.z, rd.w);
+    ps.nextD[j] = make_float4(p.nextRayDirection.x, p.nextRayDirection.y, p.nextRayDirection.z, thr.w);
+    ps.thrN[j] = make_float4(tn.x, tn.y, tn.z, p.wantsShadowRay ? 1.0f : 0.0f);
+    ps.colLit[j] = make_float4(lit.x, lit.y, lit.z, 0.0f);
+    ps.colSh[j] = make_float4(occ.x, occ.y, occ.z, 0.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// shadow: any-hit walk of the deferred shadow query, then hand over to the next bounce
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_shadow(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t lastBounce,
+         uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, unsigned long long* __restrict__ visit)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nPtr) return;
+    const float4 so = ps.shO[i];
+    const float4 tn = ps.thrN[i];
+    bool occluded = false;
+    if (tn.w != 0.0f) {
+        const float* ld = sc.scene->lights[0].direction;
+        const f3 L = normalize3(mk3(-ld[0], -ld[1], -ld[2]));     // shader.cl:471-476
+        TraceResult r;
+        traverse<2, COUNT>(A, mk3(so.x, so.y, so.z), L, tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
+        if (COUNT) flush_visits(visit, 1, r);
+        // hit -> closest-hit row 2 `shadow` sets payload.hit; miss -> row 4 `shadowMiss` clears it
+        Payload sp; sp.hit = false;
+        if (r.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[r.inst].SBTOffset + 2, sp, hh, sv, L, 0, 0, 0, false); }
+        else callMiss(4, sp);
+        occluded = sp.hit;
+    }
+    const float4 c = occluded ? ps.colSh[i] : ps.colLit[i];
+    const float4 no = ps.nextO[i], nd = ps.nextD[i];
+    if (lastBounce) {
+        store_sample(ps, nPixels, sampleBase, f2u(no.w), f2u(nd.w), mk3(c.x, c.y, c.z));
+        return;
+    }
+    ps.rayO[i] = make_float4(no.x, no.y, no.z, so.w);
+    ps.rayD[i] = make_float4(nd.x, nd.y, nd.z, no.w);
+    ps.thr[i] = make_float4(tn.x, tn.y, tn.z, nd.w);
+    ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
+// depth == 0 frames: every path ends with colour 0 without tracing
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_finalize_all(PathStreams ps, uint32_t n, uint32_t nPixels, uint32_t sampleBase)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = ps.col[i];
+    store_sample(ps, nPixels, sampleBase, f2u(ps.rayD[i].w), f2u(ps.thr[i].w), mk3(c.x, c.y, c.z));
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulate: running mean in sample order + ACES/gamma + RGBA8 (samples/shader.cl:262-304)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float aces1(float v)
+{
+    v = v * 0.6f;
+    return cl_clamp((v * (2.51f * v + 0.03f)) / (v * (2.43f * v + 0.59f) + 0.14f), 0.0f, 1.0f);
+}
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_accumulate(PathStreams ps, const uint32_t* __restrict__ owned, uint32_t nPixels, uint32_t sampleBegin,
+             uint32_t sampleCount, uint32_t totalSamples, uint32_t tonemap, uint32_t debug,
+             float* __restrict__ scratch, uint8_t* __restrict__ image)
+{
+    const uint32_t slot = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (slot >= nPixels) return;
+    const uint32_t pixel = owned ? owned[slot] : slot;
+    float4* px = reinterpret_cast<float4*>(scratch) + pixel;
+    float4 acc = *px;
+    for (uint32_t s = 0; s < sampleCount; ++s) {
+        const uint32_t frameID = totalSamples + sampleBegin + s;
+        const float4 c = ps.sampleColor[(size_t)s * nPixels + slot];
+        if (frameID == 0) { acc.x = c.x; acc.y = c.y; acc.z = c.z; }
+        else {
+            acc.x = (frameID * acc.x + c.x) / (frameID + 1);
+            acc.y = (frameID * acc.y + c.y) / (frameID + 1);
+            acc.z = (frameID * acc.z + c.z) / (frameID + 1);
+        }
+    }
+    if (sampleCount) *px = acc;
+    if (!tonemap) return;
+    f3 c = mk3(acc.x, acc.y, acc.z);
+    if (!debug) {
+        c = mk3(aces1(c.x), aces1(c.y), aces1(c.z));
+        c = mk3(powf(c.x, 0.7f), powf(c.y, 0.7f), powf(c.z, 0.7f));
+    }
+    uchar4 o;
+    o.x = (unsigned char)(int)(c.x * 255);
+    o.y = (unsigned char)(int)(c.y * 255);
+    o.z = (unsigned char)(int)(c.z * 255);
+    o.w = 255;
+    reinterpret_cast<uchar4*>(image)[pixel] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile pack / unpack for the multi-GPU framebuffer gather
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_pack_tiles(const uint8_t* __restrict__ image, uint8_t* __restrict__ packed, uint32_t w, uint32_t h, uint32_t elem,
+             uint32_t tileW, uint32_t tileH, uint32_t rank, uint32_t world, uint32_t unpack)
+{
+    // one thread per (owned pixel, 4-byte word); owned tiles are enumerated in ascending tile id
+    const uint32_t tilesX = (w + tileW - 1) / tileW, tilesY = (h + tileH - 1) / tileH;
+    const uint32_t nTiles = tilesX * tilesY;
+    const uint32_t ownedTiles = nTiles > rank ? (nTiles - rank + world - 1) / world : 0;
+    const uint32_t wordsPerPixel = elem / 4;
+    const uint64_t total = (uint64_t)ownedTiles * tileW * tileH * wordsPerPixel;
+    uint64_t g = (uint64_t)blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (g >= total) return;
+    const uint32_t word = (uint32_t)(g % wordsPerPixel);
+    const uint64_t pp = g / wordsPerPixel;
+    const uint32_t inTile = (uint32_t)(pp % (tileW * tileH));
+    const uint32_t k = (uint32_t)(pp / (tileW * tileH));
+    const uint32_t tile = rank + k * world;
+    const uint32_t x = (tile % tilesX) * tileW + inTile % tileW, y = (tile / tilesX) * tileH + inTile / tileW;
+    if (x >= w || y >= h) return;
+    const uint32_t* img = reinterpret_cast<const uint32_t*>(image);
+    uint32_t* pk = reinterpret_cast<uint32_t*>(packed);
+    const uint64_t ii = ((uint64_t)y * w + x) * wordsPerPixel + word;
+    if (unpack) const_cast<uint32_t*>(img)[ii] = pk[g];
+    else pk[g] = img[ii];
+}
+
+// ---------------------------------------------------------------------------------------------
+// test seams
+// ---------------------------------------------------------------------------------------------
+template <int REC, bool COUNT>
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_trace_batch(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, float tmin, float tmax,
+              rdx_hit* __restrict__ out, unsigned long long* __restrict__ visit)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    TraceResult r;
+    traverse<REC, COUNT>(A, ro, rd, tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
+    if (COUNT) flush_visits(visit, REC - 1, r);
+    rdx_hit h;
+    h.hit = r.hit ? 1u : 0u;
+    h.distance = r.t;
+    if (r.hit) {
+        HitInfo hi;
+        fill_hit_info(A, r.inst, ro, rd, r.t, r.b1, r.b2, r.prim, hi);
+        const DInst& I = A.insts[r.inst];
+        h.hitPoint[0] = hi.hitPoint.x; h.hitPoint[1] = hi.hitPoint.y; h.hitPoint[2] = hi.hitPoint.z;
+        h.primitiveIndex = r.prim; h.instanceIndex = I.instanceID; h.instanceCustomIndex = I.customInstanceID;
+        h.instanceSBTOffset = I.SBTOffset;
+        h.barycentric[0] = hi.bx; h.barycentric[1] = hi.by; h.barycentric[2] = hi.bz;
+        for (int k = 0; k < 16; ++k) h.transform[k] = I.fwd[k];
+    } else {
+        h.hitPoint[0] = h.hitPoint[1] = h.hitPoint[2] = 0.f;
+        h.primitiveIndex = h.instanceIndex = h.instanceCustomIndex = h.instanceSBTOffset = 0;
+        h.barycentric[0] = h.barycentric[1] = h.barycentric[2] = 0.f;
+        for (int k = 0; k < 16; ++k) h.transform[k] = 0.f;
+    }
+    out[i] = h;
+}
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_material_batch(SceneArgs sc, const rdx_hit* __restrict__ hits, const float* __restrict__ dirs,
+                 const uint32_t* __restrict__ pixels, const uint32_t* __restrict__ frames,
+                 const int32_t* __restrict__ depths, uint32_t n, rdx_payload* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const rdx_hit& hh = hits[i];
+    HitInfo h;
+    h.hitPoint = mk3(hh.hitPoint[0], hh.hitPoint[1], hh.hitPoint[2]);
+    h.bx = hh.barycentric[0]; h.by = hh.barycentric[1]; h.bz = hh.barycentric[2];
+    h.primitiveIndex = hh.primitiveIndex; h.instanceIndex = hh.instanceIndex;
+    h.fwd = hh.transform;
+    const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials};
+    Payload p;
+    p.hit = false; p.wantsShadowRay = false;
+    p.color = p.colorOccluded = p.nextFactor = p.nextRayOrigin = p.nextRayDirection = p.shadowOrigin = mk3(0.f, 0.f, 0.f);
+    material(p, h, sv, mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), frames[i], pixels[i], (uint32_t)depths[i], true);
+    rdx_payload o;
+    // colour reported for the "light visible" outcome; colorOccluded is recoverable as albedo*0.1
+    o.color[0] = p.color.x; o.color[1] = p.color.y; o.color[2] = p.color.z;
+    o.hit = p.hit ? 1u : 0u;
+    o.nextFactor[0] = p.nextFactor.x; o.nextFactor[1] = p.nextFactor.y; o.nextFactor[2] = p.nextFactor.z;
+    o.nextRayOrigin[0] = p.nextRayOrigin.x; o.nextRayOrigin[1] = p.nextRayOrigin.y; o.nextRayOrigin[2] = p.nextRayOrigin.z;
+    o.nextRayDirection[0] = p.nextRayDirection.x; o.nextRayDirection[1] = p.nextRayDirection.y; o.nextRayDirection[2] = p.nextRayDirection.z;
+    out[i] = o;
+}
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_generate_batch(CameraArgs C, const uint32_t* __restrict__ pixels, const uint32_t* __restrict__ rnd, uint32_t n,
+                 float* __restrict__ o, float* __restrict__ d)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    f3 org, dir;
+    camera_ray(C, pixels[i], pcg3d(rnd[3 * i], rnd[3 * i + 1], rnd[3 * i + 2]), org, dir);
+    o[3 * i] = org.x; o[3 * i + 1] = org.y; o[3 * i + 2] = org.z;
+    d[3 * i] = dir.x; d[3 * i + 1] = dir.y; d[3 * i + 2] = dir.z;
+}
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_pcg3d_batch(const uint32_t* __restrict__ in3, float* __restrict__ out3, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const f3 r = pcg3d(in3[3 * i], in3[3 * i + 1], in3[3 * i + 2]);
+    out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t blocks_for(uint64_t n, uint32_t b) { return (uint32_t)((n + b - 1) / b); }
+
+// threads per block for the traversal kernels: the per-lane stack lives in LDS (4 B * need * threads)
+static inline uint32_t trav_threads(uint32_t need, size_t& ldsBytes)
+{
+    uint32_t threads = RDX_BLOCK;
+    if (need < 1) need = 1;
+    while (threads > 64 && (size_t)need * threads * 4 > 40 * 1024) threads >>= 1;
+    ldsBytes = (size_t)need * threads * 4;
+    return threads;
+}
+
+void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& ps, const uint32_t* owned, uint32_t nPixels,
+                     uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples)
+{
+    const uint64_t n = (uint64_t)nPixels * sampleCount;
+    if (!n) return;
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, cam, ps, owned, nPixels,
+                       sampleBegin, sampleCount, totalSamples);
+}
+
+void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,
+                   float tmin, float tmax, unsigned long long* visit)
+{
+    if (!nMax) return;
+    size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);
+    if (visit)
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, ps, nPtr, tmin, tmax, visit);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, ps, nPtr, tmin, tmax, visit);
+}
+
+void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
+                  uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
+{
+    if (!nMax) return;
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(nMax, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, av, sc, ps, nPtr, nOut, depth,
+                       maxDepth, nPixels, sampleBase);
+}
+
+void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
+                   uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,
+                   unsigned long long* visit)
+{
+    if (!nMax) return;
+    size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);
+    if (visit)
+        hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, sc, ps, nPtr,
+                           lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax, visit);
+    else
+        hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, sc, ps, nPtr,
+                           lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax, visit);
+}
+
+void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* owned, uint32_t nPixels, uint32_t sampleBegin,
+                       uint32_t sampleCount, uint32_t totalSamples, bool tonemap, uint32_t debug, float* scratch,
+                       uint8_t* image)
+{
+    if (!nPixels) return;
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(nPixels, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, ps, owned, nPixels,
+                       sampleBegin, sampleCount, totalSamples, tonemap ? 1u : 0u, debug, scratch, image);
+}
+
+void launch_finalize_all(hipStream_t st, const PathStreams& ps, uint32_t n, uint32_t nPixels, uint32_t sampleBase)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_finalize_all, dim3(blocks_for(n, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, ps, n, nPixels, sampleBase);
+}
+
+void launch_pack_tiles(hipStream_t st, const uint8_t* image, uint8_t* packed, uint32_t w, uint32_t h, uint32_t elem,
+                       uint32_t tileW, uint32_t tileH, uint32_t rank, uint32_t world, bool unpack)
+{
+    const uint32_t tilesX = (w + tileW - 1) / tileW, tilesY = (h + tileH - 1) / tileH, nTiles = tilesX * tilesY;
+    const uint32_t ownedTiles = nTiles > rank ? (nTiles - rank + world - 1) / world : 0;
+    const uint64_t total = (uint64_t)ownedTiles * tileW * tileH * (elem / 4);
+    if (!total) return;
+    hipLaunchKernelGGL(k_pack_tiles, dim3(blocks_for(total, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, image, packed, w, h, elem,
+                       tileW, tileH, rank, world, unpack ? 1u : 0u);
+}
+
+void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, const float* d, uint32_t n, float tmin,
+                        float tmax, int rec, rdx_hit* out, unsigned long long* visit)
+{
+    if (!n) return;
+    size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);
+    const dim3 g(blocks_for(n, th)), b(th);
+    if (rec == 2) {
+        if (visit) hipLaunchKernelGGL((k_trace_batch<2, true>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
+        else hipLaunchKernelGGL((k_trace_batch<2, false>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
+    } else {
+        if (visit) hipLaunchKernelGGL((k_trace_batch<1, true>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
+        else hipLaunchKernelGGL((k_trace_batch<1, false>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
+    }
+}
+
+void launch_material_batch(hipStream_t st, const SceneArgs& sc, const rdx_hit* hits, const float* dirs,
+                           const uint32_t* pixels, const uint32_t* frames, const int32_t* depths, uint32_t n,
+                           rdx_payload* out)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_material_batch, dim3(blocks_for(n, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, sc, hits, dirs, pixels,
+                       frames, depths, n, out);
+}
+
+void launch_generate_batch(hipStream_t st, const CameraArgs& cam, const uint32_t* pixels, const uint32_t* rnd, uint32_t n,
+                           float* o, float* d)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_generate_batch, dim3(blocks_for(n, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, cam, pixels, rnd, n, o, d);
+}
+
+void launch_pcg3d_batch(hipStream_t st, const uint32_t* in3, float* out3, uint32_t n)
+{
+    if (!n) return;
+    hipLaunchKernelGGL(k_pcg3d_batch, dim3(blocks_for(n, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, in3, out3, n);
+}
+
+} // namespace rdx

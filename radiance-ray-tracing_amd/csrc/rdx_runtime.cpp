@@ -1,0 +1,852 @@
+// rdx_runtime.cpp -- host runtime behind the C ABI (include/rdx.h): device/stream singleton,
+// buffers, acceleration-structure upload + derived layout, pipeline binding and the per-frame
+// wavefront schedule.  Replaces the OpenCL host runtime of the reference
+// (radiance/src/radiance.cpp, radiance/src/clcontext.cpp) for the ray-tracing hot path.
+#include "../../include/rdx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "device_math.h"
+#include "kernels.h"
+#include "rdx_types.h"
+
+using namespace rdx;
+
+#define HIP_IGN(expr) do { (void)(expr); } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct AccelCache {                // derived traversal layout of one TLAS buffer
+    uint64_t version = ~0ull;
+    DNode* tnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
+    uint32_t stackNeed = 1;
+    void release()
+    {
+        if (tnodes) HIP_IGN(hipFree(tnodes));
+        if (insts) HIP_IGN(hipFree(insts));
+        if (bnodes) HIP_IGN(hipFree(bnodes));
+        if (tris) HIP_IGN(hipFree(tris));
+        tnodes = nullptr; insts = nullptr; bnodes = nullptr; tris = nullptr;
+    }
+};
+
+struct rdx_buffer_s {
+    void* dptr = nullptr;
+    size_t size = 0;
+    bool owned = true;
+    uint64_t version = 0;                  // bumped by every write
+    std::vector<uint8_t> shadow;           // host copy of a TLAS blob (valid iff shadowVersion == version)
+    uint64_t shadowVersion = ~0ull;
+    std::unique_ptr<AccelCache> accel;
+};
+struct rdx_blas_s { std::unique_ptr<Blas> blas; };
+struct rdx_shader_s { std::string name; bool hasRaygen = false; };
+
+namespace {
+
+struct Context {
+    bool initialized = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t evA = nullptr, evB = nullptr;
+    std::string err;
+    std::vector<std::unique_ptr<rdx_buffer_s>> buffers;
+    std::vector<std::unique_ptr<rdx_blas_s>> blases;
+    std::vector<std::unique_ptr<rdx_shader_s>> shaders;
+    rdx_shader_s* pipeline = nullptr;
+    void* slots[14] = {};
+    uint32_t nslots = 0;
+    // sharding
+    uint32_t rank = 0, world = 1, tileW = 64, tileH = 64;
+    uint32_t* ownedPixels = nullptr; uint32_t ownedCount = 0, ownedW = 0, ownedH = 0, ownedRank = 0, ownedWorld = 0,
+              ownedTileW = 0, ownedTileH = 0;
+    // path streams
+    size_t streamCap = 0, sampleCap = 0;
+    PathStreams ps{};
+    uint32_t* dCounts = nullptr;            // [0] = paths generated, [d+1] = hits of bounce d
+    uint32_t* hCounts = nullptr;            // pinned
+    unsigned long long* dVisit = nullptr;   // 8 words
+    unsigned long long* hVisit = nullptr;   // pinned
+    // options
+    int64_t chunkPaths = 16ll << 20;
+    bool countVisits = false, profiling = false;
+    rdx_trace_stats stats{};
+};
+Context g;
+
+int fail(const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g.err = buf;
+    return -1;
+}
+#define HIP_OK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail("HIP error: '%s' returned %d (%s)", #expr, (int)_e, hipGetErrorString(_e)); } while (0)
+#define HIP_OKP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail("HIP error: '%s' returned %d (%s)", #expr, (int)_e, hipGetErrorString(_e)); return nullptr; } } while (0)
+
+bool known_buffer(const void* h)
+{
+    for (auto& b : g.buffers) if (b.get() == h) return true;
+    return false;
+}
+
+// ---- derived traversal layout ------------------------------------------------------------------
+// worst-case stack occupancy of the left-first DFS in kernels.hip (right child pushed, left followed)
+uint32_t blas_need(const BlobNode* nodes, uint32_t idx)
+{
+    // iterative post-order to survive deep trees
+    struct Frame { uint32_t idx; uint32_t needL; int state; };
+    std::vector<Frame> st{{idx, 0, 0}};
+    uint32_t ret = 0;
+    while (!st.empty()) {
+        Frame& f = st.back();
+        const BlobNode& n = nodes[f.idx];
+        if (n.w0 & LEAF_BIT) { ret = 0; st.pop_back(); continue; }
+        if (f.state == 0) { f.state = 1; st.push_back({n.w0, 0, 0}); continue; }
+        if (f.state == 1) { f.needL = ret; f.state = 2; st.push_back({n.w1, 0, 0}); continue; }
+        ret = std::max(1u + f.needL, ret);
+        st.pop_back();
+    }
+    return ret;
+}
+
+int derive_accel(rdx_buffer_s* tb)
+{
+    if (tb->accel && tb->accel->version == tb->version) return 0;
+    // host copy of the blob
+    if (tb->shadowVersion != tb->version) {
+        tb->shadow.resize(tb->size);
+        HIP_OK(hipMemcpy(tb->shadow.data(), tb->dptr, tb->size, hipMemcpyDeviceToHost));
+        tb->shadowVersion = tb->version;
+    }
+    const uint8_t* blob = tb->shadow.data();
+    const size_t bsz = tb->shadow.size();
+    if (bsz < 16) return fail("TLAS buffer too small");
+    const auto* th = reinterpret_cast<const BlobTopHeader*>(blob);
+    if (th->type != TYPE_TOP_AS || th->nodeByteOffset != 16 || th->instByteOffset < 16 + sizeof(BlobNode) ||
+        th->instByteOffset > bsz || th->totalBufferSize > bsz)
+        return fail("descriptor slot 13 does not hold a top-level acceleration structure blob");
+    const uint32_t nTop = (th->instByteOffset - th->nodeByteOffset) / sizeof(BlobNode);
+    const auto* tnodes = reinterpret_cast<const BlobNode*>(blob + th->nodeByteOffset);
+    const auto* binst = reinterpret_cast<const BlobInst*>(blob + th->instByteOffset);
+    // instance count = max leaf (start+count)
+    uint32_t nInst = 0;
+    for (uint32_t i = 0; i < nTop; ++i)
+        if (tnodes[i].w0 & LEAF_BIT) nInst = std::max(nInst, tnodes[i].w1 + (tnodes[i].w0 & 0x7fffffffu));
+    if ((size_t)th->instByteOffset + (size_t)nInst * sizeof(BlobInst) > bsz) return fail("TLAS blob: instance array out of range");
+
+    std::vector<DNode> dT(nTop);
+    for (uint32_t i = 0; i < nTop; ++i) {
+        std::memcpy(&dT[i], &tnodes[i], sizeof(BlobNode));
+        if (!(tnodes[i].w0 & LEAF_BIT) && (tnodes[i].w0 >= nTop || tnodes[i].w1 >= nTop)) return fail("TLAS blob: child index out of range");
+    }
+    std::vector<DNode> dB;
+    std::vector<DTri> dTri;
+    std::vector<DInst> dI(nInst);
+    struct BlasInfo { uint32_t nodeBase; uint32_t need; };
+    std::map<uint32_t, BlasInfo> blasAt;    // byte offset -> merged-array base
+    for (uint32_t k = 0; k < nInst; ++k) {
+        const BlobInst& bi = binst[k];
+        if (bi.SBTOffset != 0)
+            return fail("instance %u has SBTOffset %u: only offset 0 (stock sbt.json rows) is supported", k, bi.SBTOffset);
+        auto it = blasAt.find(bi.instanceOffset);
+        if (it == blasAt.end()) {
+            if ((size_t)bi.instanceOffset + 16 > bsz) return fail("TLAS blob: BLAS offset out of range");
+            const uint8_t* bb = blob + bi.instanceOffset;
+            const auto* bh = reinterpret_cast<const BlobBotHeader*>(bb);
+            if (bh->type != TYPE_BOT_AS || bh->faceByteOffset < bh->nodeByteOffset || bh->vertexOffset < bh->faceByteOffset ||
+                (size_t)bi.instanceOffset + bh->vertexOffset > bsz)
+                return fail("TLAS blob: malformed bottom-level structure at byte %u", bi.instanceOffset);
+            const uint32_t nNodes = (bh->faceByteOffset - bh->nodeByteOffset) / sizeof(BlobNode);
+            const uint32_t nTris = (bh->vertexOffset - bh->faceByteOffset) / sizeof(BlobTri);
+            const auto* bn = reinterpret_cast<const BlobNode*>(bb + bh->nodeByteOffset);
+            const auto* bt = reinterpret_cast<const BlobTri*>(bb + bh->faceByteOffset);
+            const auto* bv = reinterpret_cast<const float*>(bb + bh->vertexOffset);
+            const size_t vertFloatsAvail = (bsz - bi.instanceOffset - bh->vertexOffset) / 4;
+            const uint32_t nodeBase = (uint32_t)dB.size(), triBase = (uint32_t)dTri.size();
+            if ((uint64_t)nodeBase + nNodes >= (1u << 30)) return fail("too many BVH nodes for 30-bit references");
+            dB.resize(nodeBase + nNodes);
+            for (uint32_t i = 0; i < nNodes; ++i) {
+                DNode& d = dB[nodeBase + i];
+                std::memcpy(&d, &bn[i], sizeof(BlobNode));
+                if (bn[i].w0 & LEAF_BIT) {
+                    if ((uint64_t)bn[i].w1 + (bn[i].w0 & 0x7fffffffu) > nTris) return fail("BLAS blob: leaf range out of bounds");
+                    d.w1 = bn[i].w1 + triBase;
+                } else {
+                    if (bn[i].w0 >= nNodes || bn[i].w1 >= nNodes) return fail("BLAS blob: child index out of range");
+                    d.w0 = bn[i].w0 + nodeBase; d.w1 = bn[i].w1 + nodeBase;
+                }
+            }
+            dTri.resize(triBase + nTris);
+            for (uint32_t i = 0; i < nTris; ++i) {
+                const BlobTri& t = bt[i];
+                if ((size_t)std::max({t.idx0, t.idx1, t.idx2}) * 4 + 3 > vertFloatsAvail)
+                    return fail("BLAS blob: vertex index out of range");
+                const float* v0 = bv + 4 * (size_t)t.idx0; const float* v1 = bv + 4 * (size_t)t.idx1; const float* v2 = bv + 4 * (size_t)t.idx2;
+                DTri& d = dTri[triBase + i];
+                d.v0[0] = v0[0]; d.v0[1] = v0[1]; d.v0[2] = v0[2]; d.primID = t.primID;
+                d.e1[0] = v1[0] - v0[0]; d.e1[1] = v1[1] - v0[1]; d.e1[2] = v1[2] - v0[2]; d._p0 = 0;   // radiance.cl:215
+                d.e2[0] = v2[0] - v0[0]; d.e2[1] = v2[1] - v0[1]; d.e2[2] = v2[2] - v0[2]; d._p1 = 0;   // radiance.cl:216
+            }
+            BlasInfo info{nodeBase, blas_need(bn, 0)};
+            it = blasAt.emplace(bi.instanceOffset, info).first;
+        }
+        DInst& d = dI[k];
+        std::memset(&d, 0, sizeof d);
+        std::memcpy(d.fwd, bi.m, 64);
+        inverse_mat4(bi.m, d.inv);          // zeros stay if singular (oracle convention; reference: uninitialised)
+        d.SBTOffset = bi.SBTOffset; d.instanceID = bi.instanceID; d.customInstanceID = bi.customInstanceID;
+        d.blasRoot = it->second.nodeBase;
+    }
+    // stack need: TLAS part
+    std::vector<uint32_t> needT(nTop, 0);
+    for (uint32_t i = nTop; i-- > 0;) {
+        const BlobNode& n = tnodes[i];
+        if (n.w0 & LEAF_BIT) {
+            const uint32_t cnt = n.w0 & 0x7fffffffu;
+            uint32_t mx = 0;
+            for (uint32_t k = 0; k < cnt; ++k) mx = std::max(mx, blasAt[binst[n.w1 + k].instanceOffset].need);
+            needT[i] = (cnt ? cnt - 1 : 0) + mx;
+        } else {
+            needT[i] = std::max(1u + needT[n.w0], needT[n.w1]);   // children have larger indices (DFS pre-order)
+        }
+    }
+    auto ac = std::make_unique<AccelCache>();
+    ac->stackNeed = std::max(1u, needT[0]);
+    if (ac->stackNeed > 2560) return fail("BVH too deep for the LDS traversal stack (%u entries)", ac->stackNeed);
+    auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
+        using T = typename std::remove_reference<decltype(vec)>::type::value_type;
+        const size_t bytes = std::max<size_t>(vec.size(), 1) * sizeof(T);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&dptr), bytes);
+        if (e != hipSuccess) return e;
+        return vec.empty() ? hipSuccess : hipMemcpy(dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice);
+    };
+    HIP_OK(up(ac->tnodes, dT));
+    HIP_OK(up(ac->insts, dI));
+    HIP_OK(up(ac->bnodes, dB));
+    HIP_OK(up(ac->tris, dTri));
+    ac->version = tb->version;
+    if (tb->accel) tb->accel->release();
+    tb->accel = std::move(ac);
+    return 0;
+}
+
+AccelView view_of(const rdx_buffer_s* tb)
+{
+    AccelView v{};
+    v.tnodes = tb->accel->tnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
+    v.stackNeed = tb->accel->stackNeed;
+    return v;
+}
+
+// ---- path streams --------------------------------------------------------------------------------
+int ensure_streams(size_t paths, size_t samplesTimesPixels)
+{
+    if (paths > g.streamCap) {
+        float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.shO, &g.ps.nextO,
+                          &g.ps.nextD, &g.ps.thrN, &g.ps.colLit, &g.ps.colSh};
+        for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
+        if (g.ps.hitInst) HIP_IGN(hipFree(g.ps.hitInst));
+        g.ps.hitInst = nullptr;
+        g.streamCap = 0;
+        for (auto a : arr) HIP_OK(hipMalloc(reinterpret_cast<void**>(a), paths * sizeof(float4)));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.ps.hitInst), paths * sizeof(uint32_t)));
+        g.streamCap = paths;
+    }
+    if (samplesTimesPixels > g.sampleCap) {
+        if (g.ps.sampleColor) HIP_IGN(hipFree(g.ps.sampleColor));
+        g.ps.sampleColor = nullptr; g.sampleCap = 0;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.ps.sampleColor), samplesTimesPixels * sizeof(float4)));
+        g.sampleCap = samplesTimesPixels;
+    }
+    return 0;
+}
+
+// pixels owned by (rank, world) for a w x h image, ascending tile id, row-major inside a tile
+void owned_pixel_list(uint32_t w, uint32_t h, uint32_t tileW, uint32_t tileH, uint32_t rank, uint32_t world,
+                      std::vector<uint32_t>& out)
+{
+    const uint32_t tilesX = (w + tileW - 1) / tileW, tilesY = (h + tileH - 1) / tileH;
+    out.clear();
+    for (uint32_t t = rank; t < tilesX * tilesY; t += world) {
+        const uint32_t x0 = (t % tilesX) * tileW, y0 = (t / tilesX) * tileH;
+        for (uint32_t y = y0; y < std::min(h, y0 + tileH); ++y)
+            for (uint32_t x = x0; x < std::min(w, x0 + tileW); ++x) out.push_back(y * w + x);
+    }
+}
+
+int ensure_owned(uint32_t w, uint32_t h)
+{
+    if (g.world <= 1) { g.ownedCount = w * h; return 0; }
+    if (g.ownedPixels && g.ownedW == w && g.ownedH == h && g.ownedRank == g.rank && g.ownedWorld == g.world &&
+        g.ownedTileW == g.tileW && g.ownedTileH == g.tileH)
+        return 0;
+    std::vector<uint32_t> px;
+    owned_pixel_list(w, h, g.tileW, g.tileH, g.rank, g.world, px);
+    if (g.ownedPixels) HIP_IGN(hipFree(g.ownedPixels));
+    g.ownedPixels = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.ownedPixels), std::max<size_t>(px.size(), 1) * 4));
+    if (!px.empty()) HIP_OK(hipMemcpy(g.ownedPixels, px.data(), px.size() * 4, hipMemcpyHostToDevice));
+    g.ownedCount = (uint32_t)px.size();
+    g.ownedW = w; g.ownedH = h; g.ownedRank = g.rank; g.ownedWorld = g.world; g.ownedTileW = g.tileW; g.ownedTileH = g.tileH;
+    return 0;
+}
+
+void camera_args(const PhysicalCamera& cam, CameraArgs& C)
+{
+    C.cam = cam;
+    // EulerX/Y/ZToMat4x4 (math.cl:185-252): per-frame constants, evaluated once with libm
+    const float cx = cosf(cam.wx), sx = sinf(cam.wx), cy = cosf(cam.wy), sy = sinf(cam.wy), cz = cosf(cam.wz), sz = sinf(cam.wz);
+    const float rx[16] = {1, 0, 0, 0, 0, cx, -sx, 0, 0, sx, cx, 0, 0, 0, 0, 1};
+    const float ry[16] = {cy, 0, sy, 0, 0, 1, 0, 0, -sy, 0, cy, 0, 0, 0, 0, 1};
+    const float rz[16] = {cz, -sz, 0, 0, sz, cz, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(C.rotX, rx, 64); std::memcpy(C.rotY, ry, 64); std::memcpy(C.rotZ, rz, 64);
+}
+
+int scene_args(SceneArgs& sc)
+{
+    for (int i : {4, 5, 7, 8, 9, 10})
+        if (!g.slots[i] || !known_buffer(g.slots[i])) return fail("descriptor slot %d is not a buffer", i);
+    auto ptr = [&](int i) { return static_cast<rdx_buffer_s*>(g.slots[i])->dptr; };
+    sc.scene = static_cast<const SceneProperties*>(ptr(4));
+    sc.meshInfo = static_cast<const MeshInfo*>(ptr(5));
+    sc.indexData = static_cast<const uint32_t*>(ptr(7));
+    sc.uvData = static_cast<const float*>(ptr(8));
+    sc.normalData = static_cast<const float*>(ptr(9));
+    sc.materials = static_cast<const Material*>(ptr(10));
+    if (static_cast<rdx_buffer_s*>(g.slots[4])->size < sizeof(SceneProperties)) return fail("scene buffer smaller than SceneProperties");
+    return 0;
+}
+
+struct StageTimer {
+    // per-stage HIP-event timing (profiling mode): events are recorded around each launch and
+    // resolved after the frame so that the stream is never drained in the middle
+    struct Span { hipEvent_t a, b; float* dst; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get()
+    {
+        if (used == pool.size()) { hipEvent_t e; HIP_IGN(hipEventCreate(&e)); pool.push_back(e); }
+        return pool[used++];
+    }
+    void begin(float* dst) { if (!g.profiling) return; Span s{get(), get(), dst}; HIP_IGN(hipEventRecord(s.a, g.stream)); spans.push_back(s); }
+    void end() { if (!g.profiling) return; HIP_IGN(hipEventRecord(spans.back().b, g.stream)); }
+    void resolve()
+    {
+        for (auto& s : spans) { float ms = 0; HIP_IGN(hipEventElapsedTime(&ms, s.a, s.b)); *s.dst += ms; }
+        spans.clear(); used = 0;
+    }
+};
+StageTimer g_timer;
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+// platform
+// ------------------------------------------------------------------------------------------------
+extern "C" int rdx_init(int device)
+{
+    if (g.initialized) return 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail("no HIP device available (hipGetDeviceCount -> %d, count %d): the ray-tracing core needs a GPU", (int)e, count);
+    if (device < 0) { HIP_OK(hipGetDevice(&device)); }
+    if (device >= count) return fail("device ordinal %d out of range (%d devices)", device, count);
+    HIP_OK(hipSetDevice(device));
+    g.device = device;
+    HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreate(&g.evA));
+    HIP_OK(hipEventCreate(&g.evB));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dCounts), 64 * sizeof(uint32_t)));
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hCounts), 64 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dVisit), 8 * sizeof(unsigned long long)));
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hVisit), 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    g.initialized = true;
+    return 0;
+}
+
+extern "C" int rdx_shutdown(void)
+{
+    if (!g.initialized) return 0;
+    HIP_IGN(hipStreamSynchronize(g.stream));
+    for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
+    g.buffers.clear(); g.blases.clear(); g.shaders.clear();
+    float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.shO, &g.ps.nextO, &g.ps.nextD,
+                      &g.ps.thrN, &g.ps.colLit, &g.ps.colSh, &g.ps.sampleColor};
+    for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
+    if (g.ps.hitInst) HIP_IGN(hipFree(g.ps.hitInst));
+    if (g.ownedPixels) HIP_IGN(hipFree(g.ownedPixels));
+    if (g.dCounts) HIP_IGN(hipFree(g.dCounts));
+    if (g.hCounts) HIP_IGN(hipHostFree(g.hCounts));
+    if (g.dVisit) HIP_IGN(hipFree(g.dVisit));
+    if (g.hVisit) HIP_IGN(hipHostFree(g.hVisit));
+    HIP_IGN(hipEventDestroy(g.evA)); HIP_IGN(hipEventDestroy(g.evB));
+    HIP_IGN(hipStreamDestroy(g.stream));
+    g = Context{};
+    return 0;
+}
+
+extern "C" const char* rdx_last_error(void) { return g.err.c_str(); }
+
+extern "C" int rdx_device_name(char* out, size_t cap)
+{
+    if (!g.initialized) return fail("rdx_init has not been called");
+    hipDeviceProp_t p;
+    HIP_OK(hipGetDeviceProperties(&p, g.device));
+    snprintf(out, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// buffers
+// ------------------------------------------------------------------------------------------------
+extern "C" rdx_buffer rdx_buffer_create(size_t size)
+{
+    if (!g.initialized) { fail("rdx_init has not been called"); return nullptr; }
+    auto b = std::make_unique<rdx_buffer_s>();
+    b->size = size;
+    HIP_OKP(hipMalloc(&b->dptr, std::max<size_t>(size, 16)));
+    HIP_OKP(hipMemset(b->dptr, 0, std::max<size_t>(size, 16)));
+    g.buffers.push_back(std::move(b));
+    return g.buffers.back().get();
+}
+
+extern "C" rdx_buffer rdx_buffer_wrap(void* device_ptr, size_t size)
+{
+    if (!g.initialized) { fail("rdx_init has not been called"); return nullptr; }
+    if (!device_ptr) { fail("rdx_buffer_wrap: null device pointer"); return nullptr; }
+    auto b = std::make_unique<rdx_buffer_s>();
+    b->size = size; b->dptr = device_ptr; b->owned = false;
+    g.buffers.push_back(std::move(b));
+    return g.buffers.back().get();
+}
+
+extern "C" int rdx_buffer_write(rdx_buffer b, size_t offset, size_t size, const void* src)
+{
+    if (!b || !known_buffer(b)) return fail("WriteBuffer: invalid buffer handle");
+    if (offset + size > b->size) return fail("WriteBuffer: range [%zu, %zu) exceeds buffer size %zu", offset, offset + size, b->size);
+    if (size) HIP_OK(hipMemcpy(static_cast<uint8_t*>(b->dptr) + offset, src, size, hipMemcpyHostToDevice));
+    b->version++;
+    return 0;
+}
+
+extern "C" int rdx_buffer_read(rdx_buffer b, size_t offset, size_t size, void* dst)
+{
+    if (!b || !known_buffer(b)) return fail("ReadBuffer: invalid buffer handle");
+    if (offset + size > b->size) return fail("ReadBuffer: range [%zu, %zu) exceeds buffer size %zu", offset, offset + size, b->size);
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (size) HIP_OK(hipMemcpy(dst, static_cast<const uint8_t*>(b->dptr) + offset, size, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" void* rdx_buffer_device_ptr(rdx_buffer b) { return (b && known_buffer(b)) ? b->dptr : nullptr; }
+extern "C" size_t rdx_buffer_size(rdx_buffer b) { return (b && known_buffer(b)) ? b->size : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// acceleration structures
+// ------------------------------------------------------------------------------------------------
+extern "C" rdx_blas rdx_blas_build(const float* v, uint32_t nv, const uint32_t* idx, uint32_t nt)
+{
+    std::string err;
+    Blas* b = build_blas(v, nv, idx, nt, err);
+    if (!b) { fail("%s", err.c_str()); return nullptr; }
+    auto h = std::make_unique<rdx_blas_s>();
+    h->blas.reset(b);
+    g.blases.push_back(std::move(h));
+    return g.blases.back().get();
+}
+
+extern "C" const void* rdx_blas_data(rdx_blas b, uint32_t* size_out)
+{
+    if (!b) return nullptr;
+    if (size_out) *size_out = (uint32_t)b->blas->data.size();
+    return b->blas->data.data();
+}
+extern "C" int rdx_blas_max_depth(rdx_blas b) { return b ? b->blas->maxDepth : -1; }
+
+static rdx_buffer tlas_from_blob(std::vector<uint8_t>&& blob)
+{
+    rdx_buffer tb = rdx_buffer_create(blob.size());
+    if (!tb) return nullptr;
+    if (rdx_buffer_write(tb, 0, blob.size(), blob.data()) != 0) return nullptr;
+    tb->shadow = std::move(blob);
+    tb->shadowVersion = tb->version;
+    return tb;
+}
+
+static bool tlas_blob(const rdx_instance* inst, uint32_t n, std::vector<uint8_t>& blob, int& depth)
+{
+    std::vector<InstanceDesc> d(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memcpy(d[i].transform, inst[i].transform, 64);
+        d[i].SBTOffset = inst[i].SBTOffset;
+        d[i].customInstanceID = inst[i].customInstanceID;
+        d[i].blas = inst[i].bottomAccelStruct ? inst[i].bottomAccelStruct->blas.get() : nullptr;
+    }
+    std::string err;
+    if (!build_tlas(d.data(), n, blob, depth, err)) { fail("%s", err.c_str()); return false; }
+    return true;
+}
+
+extern "C" void* rdx_tlas_build_blob(const rdx_instance* inst, uint32_t n, uint32_t* size_out, int* max_depth_out)
+{
+    std::vector<uint8_t> blob;
+    int depth = 0;
+    if (!tlas_blob(inst, n, blob, depth)) return nullptr;
+    void* p = malloc(blob.size());
+    if (!p) { fail("out of memory"); return nullptr; }
+    std::memcpy(p, blob.data(), blob.size());
+    if (size_out) *size_out = (uint32_t)blob.size();
+    if (max_depth_out) *max_depth_out = depth;
+    return p;
+}
+extern "C" void rdx_free(void* p) { free(p); }
+
+extern "C" rdx_buffer rdx_tlas_build(const rdx_instance* inst, uint32_t n)
+{
+    if (!g.initialized) { fail("rdx_init has not been called"); return nullptr; }
+    std::vector<uint8_t> blob;
+    int depth = 0;
+    if (!tlas_blob(inst, n, blob, depth)) return nullptr;
+    return tlas_from_blob(std::move(blob));
+}
+
+// radiance.cpp:428-448: raw dump of the TLAS buffer, size from header word 3
+extern "C" int rdx_tlas_to_file(rdx_buffer tlas, const char* path)
+{
+    if (!tlas || !known_buffer(tlas)) return fail("TopAccelStructToFile: invalid handle");
+    BlobTopHeader hdr;
+    if (rdx_buffer_read(tlas, 0, sizeof hdr, &hdr)) return -1;
+    if (hdr.totalBufferSize > tlas->size) return fail("TopAccelStructToFile: header size %u exceeds buffer size %zu", hdr.totalBufferSize, tlas->size);
+    std::vector<uint8_t> data(hdr.totalBufferSize);
+    if (rdx_buffer_read(tlas, 0, data.size(), data.data())) return -1;
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return fail("TopAccelStructToFile: cannot open '%s' for writing", path);
+    const size_t wr = fwrite(data.data(), 1, data.size(), fp);
+    fclose(fp);
+    return wr == data.size() ? 0 : fail("TopAccelStructToFile: short write to '%s'", path);
+}
+
+// radiance.cpp:450-479
+extern "C" rdx_buffer rdx_tlas_from_file(const char* path)
+{
+    if (!g.initialized) { fail("rdx_init has not been called"); return nullptr; }
+    FILE* fp = fopen(path, "rb");
+    if (!fp) { fail("FileToTopAccelStruct: cannot open '%s'", path); return nullptr; }
+    BlobTopHeader hdr;
+    if (fread(&hdr, 1, sizeof hdr, fp) != sizeof hdr) { fclose(fp); fail("FileToTopAccelStruct: short read of header in '%s'", path); return nullptr; }
+    if (hdr.type != TYPE_TOP_AS || hdr.totalBufferSize < sizeof hdr) { fclose(fp); fail("FileToTopAccelStruct: '%s' is not a TLAS cache file", path); return nullptr; }
+    std::vector<uint8_t> data(hdr.totalBufferSize);
+    rewind(fp);
+    const size_t rd = fread(data.data(), 1, data.size(), fp);
+    fclose(fp);
+    if (rd != data.size()) { fail("FileToTopAccelStruct: short read of '%s' (%zu of %zu bytes)", path, rd, data.size()); return nullptr; }
+    return tlas_from_blob(std::move(data));
+}
+
+// ------------------------------------------------------------------------------------------------
+// pipeline
+// ------------------------------------------------------------------------------------------------
+static bool has_identifier(const std::string& text, const char* name)
+{
+    const size_t n = strlen(name);
+    size_t pos = 0;
+    auto isid = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; };
+    while ((pos = text.find(name, pos)) != std::string::npos) {
+        const bool l = pos == 0 || !isid(text[pos - 1]);
+        const bool r = pos + n >= text.size() || !isid(text[pos + n]);
+        if (l && r) return true;
+        pos += n;
+    }
+    return false;
+}
+
+extern "C" rdx_shader rdx_shader_module_create(const char* code, uint32_t size, const char* name)
+{
+    if (!g.initialized) { fail("rdx_init has not been called"); return nullptr; }
+    if (!code) { fail("CreateShaderModule: null shader text"); return nullptr; }
+    const std::string text(code, size);
+    // The reference JIT-compiles `code` and takes the kernel named "raygen" (radiance.cpp:177); the
+    // stage functions it dispatches to are those of samples/sbt.json, which this library ships as
+    // hand-written HIP stages.  Accept the text if it declares that entry point.
+    if (!has_identifier(text, "raygen")) {
+        fail("CreateShaderModule: shader text has no `raygen` kernel (clCreateKernel(\"raygen\") would fail)");
+        return nullptr;
+    }
+    auto s = std::make_unique<rdx_shader_s>();
+    s->name = name ? name : "";
+    s->hasRaygen = true;
+    g.shaders.push_back(std::move(s));
+    return g.shaders.back().get();
+}
+
+extern "C" int rdx_bind_pipeline(rdx_shader m)
+{
+    if (!m) return fail("BindPipeline: null shader module");
+    g.pipeline = m;
+    return 0;
+}
+
+extern "C" int rdx_bind_descriptor_set(void* const* handles, uint32_t n)
+{
+    if (!g.pipeline) return fail("BindDescriptorSet: no pipeline bound");
+    if (n > 14) return fail("BindDescriptorSet: %u descriptors, the raygen stage takes 14", n);
+    for (uint32_t i = 0; i < n; ++i) g.slots[i] = handles[i];
+    g.nslots = std::max(g.nslots, n);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sharding
+// ------------------------------------------------------------------------------------------------
+extern "C" int rdx_set_shard(uint32_t rank, uint32_t world, uint32_t tw, uint32_t th)
+{
+    if (world == 0 || rank >= world || tw == 0 || th == 0) return fail("rdx_set_shard: invalid rank/world/tile");
+    g.rank = rank; g.world = world; g.tileW = tw; g.tileH = th;
+    return 0;
+}
+
+extern "C" uint32_t rdx_shard_pixel_count(uint32_t w, uint32_t h, uint32_t rank, uint32_t world)
+{
+    std::vector<uint32_t> px;
+    owned_pixel_list(w, h, g.tileW, g.tileH, rank, world, px);
+    return (uint32_t)px.size();
+}
+
+static int pack_impl(rdx_buffer image, rdx_buffer packed, uint32_t w, uint32_t h, uint32_t elem, uint32_t rank,
+                     uint32_t world, bool unpack)
+{
+    if (!image || !packed || !known_buffer(image) || !known_buffer(packed)) return fail("pack_tiles: invalid buffer");
+    if (elem % 4 || elem == 0) return fail("pack_tiles: element size must be a multiple of 4");
+    const uint32_t tilesX = (w + g.tileW - 1) / g.tileW, tilesY = (h + g.tileH - 1) / g.tileH, nT = tilesX * tilesY;
+    const uint32_t owned = nT > rank ? (nT - rank + world - 1) / world : 0;
+    if ((size_t)w * h * elem > image->size) return fail("pack_tiles: image buffer too small");
+    if ((size_t)owned * g.tileW * g.tileH * elem > packed->size) return fail("pack_tiles: packed buffer too small");
+    launch_pack_tiles(g.stream, static_cast<uint8_t*>(image->dptr), static_cast<uint8_t*>(packed->dptr), w, h, elem,
+                      g.tileW, g.tileH, rank, world, unpack);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (unpack) image->version++; else packed->version++;
+    return 0;
+}
+extern "C" int rdx_pack_tiles(rdx_buffer image, rdx_buffer packed, uint32_t w, uint32_t h, uint32_t elem, uint32_t rank, uint32_t world)
+{ return pack_impl(image, packed, w, h, elem, rank, world, false); }
+extern "C" int rdx_unpack_tiles(rdx_buffer packed, rdx_buffer image, uint32_t w, uint32_t h, uint32_t elem, uint32_t rank, uint32_t world)
+{ return pack_impl(image, packed, w, h, elem, rank, world, true); }
+
+// ------------------------------------------------------------------------------------------------
+// TraceRays
+// ------------------------------------------------------------------------------------------------
+extern "C" int rdx_set_profiling(int on) { g.profiling = on != 0; return 0; }
+extern "C" int rdx_set_option(const char* name, int64_t value)
+{
+    if (!name) return fail("rdx_set_option: null name");
+    if (!strcmp(name, "chunk_paths")) { if (value < 1) return fail("chunk_paths must be >= 1"); g.chunkPaths = value; return 0; }
+    if (!strcmp(name, "count_visits")) { g.countVisits = value != 0; return 0; }
+    return fail("rdx_set_option: unknown option '%s'", name);
+}
+extern "C" int rdx_get_trace_stats(rdx_trace_stats* out) { if (!out) return fail("null"); *out = g.stats; return 0; }
+
+extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint32_t height)
+{
+    if (!g.initialized) return fail("rdx_init has not been called");
+    if (!g.pipeline) return fail("TraceRays: no pipeline bound");
+    if (g.nslots < 14) return fail("TraceRays: %u descriptors bound, the raygen stage takes 14", g.nslots);
+    for (int i : {0, 1, 2, 3, 13})
+        if (!g.slots[i] || !known_buffer(g.slots[i])) return fail("descriptor slot %d is not a buffer", i);
+    auto* bRT = static_cast<rdx_buffer_s*>(g.slots[0]);
+    auto* bScratch = static_cast<rdx_buffer_s*>(g.slots[1]);
+    auto* bImage = static_cast<rdx_buffer_s*>(g.slots[2]);
+    auto* bCam = static_cast<rdx_buffer_s*>(g.slots[3]);
+    auto* bTlas = static_cast<rdx_buffer_s*>(g.slots[13]);
+    const uint64_t nPix = (uint64_t)width * height;
+    if (nPix == 0) return 0;
+    if (nPix > 0x7fffffffull) return fail("TraceRays: %llu pixels exceed the 31-bit pixel index", (unsigned long long)nPix);
+    if (bRT->size < sizeof(RayTraceProperties) || bCam->size < sizeof(PhysicalCamera)) return fail("TraceRays: RTProp / camera buffer too small");
+    if (bScratch->size < nPix * 16) return fail("TraceRays: imageScratch holds %zu bytes, %llu needed", bScratch->size, (unsigned long long)nPix * 16);
+    if (bImage->size < nPix * 4) return fail("TraceRays: image holds %zu bytes, %llu needed", bImage->size, (unsigned long long)nPix * 4);
+
+    SceneArgs sc;
+    if (scene_args(sc)) return -1;
+    if (derive_accel(bTlas)) return -1;
+    const AccelView av = view_of(bTlas);
+
+    // per-frame constants live in device buffers the caller may have rewritten (sample1.cpp:480-490)
+    RayTraceProperties rt; PhysicalCamera cam;
+    HIP_OK(hipMemcpy(&rt, bRT->dptr, sizeof rt, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&cam, bCam->dptr, sizeof cam, hipMemcpyDeviceToHost));
+    CameraArgs C;
+    camera_args(cam, C);
+    if ((uint32_t)cam.widthPixel == 0) return fail("TraceRays: camera widthPixel is 0");
+
+    if (ensure_owned(width, height)) return -1;
+    const uint32_t P = g.ownedCount;
+    const uint32_t* owned = g.world > 1 ? g.ownedPixels : nullptr;
+
+    // depth as the raygen loop sees it: `debug` breaks after the first bounce (shader.cl:256-259)
+    uint32_t maxDepth = rt.depth;
+    if (rt.debug && maxDepth > 1) maxDepth = 1;
+    if (maxDepth > 62) return fail("TraceRays: depth %u exceeds the supported maximum of 62", maxDepth);
+
+    std::memset(&g.stats, 0, sizeof g.stats);
+    g.stats.pixels = P;
+    unsigned long long* visit = g.countVisits ? g.dVisit : nullptr;
+    if (visit) HIP_OK(hipMemsetAsync(g.dVisit, 0, 8 * sizeof(unsigned long long), g.stream));
+
+    HIP_OK(hipEventRecord(g.evA, g.stream));
+    const uint32_t batch = rt.batchSize;
+    uint32_t samplesPerChunk = batch;
+    if (P && (uint64_t)batch * P > (uint64_t)g.chunkPaths) samplesPerChunk = (uint32_t)std::max<int64_t>(1, g.chunkPaths / P);
+    if (P && batch) { if (ensure_streams((size_t)samplesPerChunk * P, (size_t)samplesPerChunk * P)) return -1; }
+
+    const float tmin = 0.001f, tmax = 1000.0f;      // shader.cl:235-236, 500
+    for (uint32_t s0 = 0; s0 < batch && P; s0 += samplesPerChunk) {
+        const uint32_t sc_n = std::min(samplesPerChunk, batch - s0);
+        const uint32_t n0 = sc_n * P;
+        const uint32_t sampleBase = rt.totalSamples + s0;
+        // counts[0] = n0, counts[1..] = 0
+        std::memset(g.hCounts, 0, 64 * sizeof(uint32_t));
+        g.hCounts[0] = n0;
+        HIP_OK(hipMemcpyAsync(g.dCounts, g.hCounts, 64 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+
+        g_timer.begin(&g.stats.ms_generate);
+        launch_generate(g.stream, C, g.ps, owned, P, s0, sc_n, rt.totalSamples);
+        g_timer.end();
+        if (maxDepth == 0) {
+            launch_finalize_all(g.stream, g.ps, n0, P, sampleBase);
+        }
+        for (uint32_t d = 0; d < maxDepth; ++d) {
+            g_timer.begin(&g.stats.ms_extend);
+            launch_extend(g.stream, av, g.ps, g.dCounts + d, n0, tmin, tmax, visit);
+            g_timer.end();
+            g.stats.launches_extend++;
+            g_timer.begin(&g.stats.ms_shade);
+            launch_shade(g.stream, av, sc, g.ps, g.dCounts + d, g.dCounts + d + 1, n0, d, maxDepth, P, sampleBase);
+            g_timer.end();
+            g_timer.begin(&g.stats.ms_shadow);
+            launch_shadow(g.stream, av, sc, g.ps, g.dCounts + d + 1, n0, d + 1 == maxDepth, P, sampleBase, tmin, tmax, visit);
+            g_timer.end();
+            g.stats.launches_shadow++;
+        }
+        g_timer.begin(&g.stats.ms_accumulate);
+        launch_accumulate(g.stream, g.ps, owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
+                          static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
+        g_timer.end();
+        HIP_OK(hipMemcpyAsync(g.hCounts, g.dCounts, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+        HIP_OK(hipStreamSynchronize(g.stream));
+        if (maxDepth) g.stats.rays_primary += g.hCounts[0];
+        for (uint32_t d = 1; d < maxDepth; ++d) g.stats.rays_bounce += g.hCounts[d];
+        for (uint32_t d = 0; d < maxDepth; ++d) { g.stats.rays_shadow += g.hCounts[d + 1]; g.stats.closest_hits += g.hCounts[d + 1]; }
+    }
+    if (batch == 0 && P) {
+        // no samples: only the tonemap of the existing accumulator runs (shader.cl:283-304)
+        launch_accumulate(g.stream, g.ps, owned, P, 0, 0, rt.totalSamples, true, rt.debug,
+                          static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
+    }
+    HIP_OK(hipEventRecord(g.evB, g.stream));
+    if (visit) HIP_OK(hipMemcpyAsync(g.hVisit, g.dVisit, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));          // clFinish (radiance.cpp:261)
+    HIP_OK(hipEventElapsedTime(&g.stats.ms_total, g.evA, g.evB));
+    g_timer.resolve();
+    if (visit)
+        for (int c = 0; c < 2; ++c) {
+            g.stats.visit_top_nodes[c] = g.hVisit[c * 4 + 0]; g.stats.visit_instances[c] = g.hVisit[c * 4 + 1];
+            g.stats.visit_bot_nodes[c] = g.hVisit[c * 4 + 2]; g.stats.visit_triangles[c] = g.hVisit[c * 4 + 3];
+        }
+    bScratch->version++; bImage->version++;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// test seams
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <class T> struct DevArray {
+    T* p = nullptr;
+    ~DevArray() { if (p) HIP_IGN(hipFree(p)); }
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T)); }
+    hipError_t upload(const T* src, size_t n) { hipError_t e = alloc(n); if (e != hipSuccess || !n) return e; return hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice); }
+};
+}
+
+extern "C" int rdx_trace_batch(rdx_buffer tlas, const float* o, const float* d, uint32_t n, float tmin, float tmax,
+                               int rec, rdx_hit* out, uint64_t* visit4)
+{
+    if (!g.initialized) return fail("rdx_init has not been called");
+    if (!tlas || !known_buffer(tlas)) return fail("rdx_trace_batch: invalid TLAS handle");
+    if (rec != 1 && rec != 2) return fail("rdx_trace_batch: sbtRecordOffset must be 1 or 2");
+    if (derive_accel(tlas)) return -1;
+    DevArray<float> dO, dD; DevArray<rdx_hit> dH;
+    HIP_OK(dO.upload(o, 3 * (size_t)n)); HIP_OK(dD.upload(d, 3 * (size_t)n)); HIP_OK(dH.alloc(n));
+    if (visit4) HIP_OK(hipMemsetAsync(g.dVisit, 0, 8 * sizeof(unsigned long long), g.stream));
+    launch_trace_batch(g.stream, view_of(tlas), dO.p, dD.p, n, tmin, tmax, rec, dH.p, visit4 ? g.dVisit : nullptr);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (n) HIP_OK(hipMemcpy(out, dH.p, (size_t)n * sizeof(rdx_hit), hipMemcpyDeviceToHost));
+    if (visit4) {
+        unsigned long long v[8];
+        HIP_OK(hipMemcpy(v, g.dVisit, sizeof v, hipMemcpyDeviceToHost));
+        for (int k = 0; k < 4; ++k) visit4[k] = v[(rec - 1) * 4 + k];
+    }
+    return 0;
+}
+
+extern "C" int rdx_material_batch(const rdx_hit* hits, const float* dirs, const uint32_t* pixels, const uint32_t* frames,
+                                  const int32_t* depths, uint32_t n, rdx_payload* out)
+{
+    if (!g.initialized) return fail("rdx_init has not been called");
+    SceneArgs sc;
+    if (scene_args(sc)) return -1;
+    DevArray<rdx_hit> dH; DevArray<float> dD; DevArray<uint32_t> dP, dF; DevArray<int32_t> dDep; DevArray<rdx_payload> dO;
+    HIP_OK(dH.upload(hits, n)); HIP_OK(dD.upload(dirs, 3 * (size_t)n)); HIP_OK(dP.upload(pixels, n));
+    HIP_OK(dF.upload(frames, n)); HIP_OK(dDep.upload(depths, n)); HIP_OK(dO.alloc(n));
+    launch_material_batch(g.stream, sc, dH.p, dD.p, dP.p, dF.p, dDep.p, n, dO.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (n) HIP_OK(hipMemcpy(out, dO.p, (size_t)n * sizeof(rdx_payload), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rdx_generate_batch(const uint32_t* pixels, const uint32_t* rnd, uint32_t n, float* o, float* d)
+{
+    if (!g.initialized) return fail("rdx_init has not been called");
+    if (!g.slots[3] || !known_buffer(g.slots[3])) return fail("descriptor slot 3 (camera) is not a buffer");
+    PhysicalCamera cam;
+    HIP_OK(hipMemcpy(&cam, static_cast<rdx_buffer_s*>(g.slots[3])->dptr, sizeof cam, hipMemcpyDeviceToHost));
+    CameraArgs C;
+    camera_args(cam, C);
+    DevArray<uint32_t> dP, dR; DevArray<float> dO, dD;
+    HIP_OK(dP.upload(pixels, n)); HIP_OK(dR.upload(rnd, 3 * (size_t)n)); HIP_OK(dO.alloc(3 * (size_t)n)); HIP_OK(dD.alloc(3 * (size_t)n));
+    launch_generate_batch(g.stream, C, dP.p, dR.p, n, dO.p, dD.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (n) { HIP_OK(hipMemcpy(o, dO.p, 12 * (size_t)n, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(d, dD.p, 12 * (size_t)n, hipMemcpyDeviceToHost)); }
+    return 0;
+}
+
+extern "C" int rdx_pcg3d_batch(const uint32_t* in3, float* out3, uint32_t n)
+{
+    if (!g.initialized) return fail("rdx_init has not been called");
+    DevArray<uint32_t> dI; DevArray<float> dO;
+    HIP_OK(dI.upload(in3, 3 * (size_t)n)); HIP_OK(dO.alloc(3 * (size_t)n));
+    launch_pcg3d_batch(g.stream, dI.p, dO.p, n);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (n) HIP_OK(hipMemcpy(out3, dO.p, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}

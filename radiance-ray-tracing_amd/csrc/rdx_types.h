@@ -1,0 +1,62 @@
+// rdx_types.h -- POD layouts shared by the host runtime, the BVH builder and the HIP kernels.
+//
+// "Blob" structs are the reference's on-device acceleration-structure format
+// (radiance/shader/data.cl:4-83 == radiance/src/core.h:34-101); the product keeps producing and
+// accepting that byte format at the API boundary (TLAS cache files, ReadBuffer of a TLAS).
+// "D*" structs are the traversal-friendly layout derived from a blob at first use: same float
+// values, laid out for 16-byte coalesced loads and without the dependent vertex fetch.
+#pragma once
+#include <stdint.h>
+
+namespace rdx {
+
+// ---- reference blob format -------------------------------------------------------------------
+struct BlobTopHeader { uint32_t type, nodeByteOffset, instByteOffset, totalBufferSize; };   // core.h:34-40
+struct BlobBotHeader { uint32_t type, nodeByteOffset, faceByteOffset, vertexOffset; };      // core.h:42-48
+struct BlobNode {                                                                           // core.h:59-87 (48 B)
+    float bottom[4];
+    float top[4];
+    uint32_t w0, w1, w2, w3;   // inner: {left, right, 0, 0}; leaf: {0x80000000|count, start, type, 0}
+};
+struct BlobTri  { uint32_t idx0, idx1, idx2, primID; };                                     // core.h:90-96
+struct BlobInst { float m[16]; uint32_t SBTOffset, instanceID, customInstanceID, instanceOffset; }; // core.h:50-57 (80 B)
+
+enum : uint32_t { TYPE_INST = 1, TYPE_TRIG = 2, TYPE_TOP_AS = 1, TYPE_BOT_AS = 2, LEAF_BIT = 0x80000000u };
+
+// ---- host structs bound to the raygen stage (core.h:103-158) ----------------------------------
+struct RayTraceProperties { uint32_t totalSamples, batchSize, depth, debug; };
+struct Material { float albedo[4]; float metallic, roughness, transmission, ior;
+                  int32_t albedoTexIdx, metallicTexIdx, roughnessTexIdx, normalTexIdx; };
+struct MeshInfo { int32_t vertexOffset, indexOffset, uvOffset, normalOffset, materialIndex, _0, _1, _2; };
+struct DirLight { float direction[4]; float color[4]; };
+struct SceneProperties { uint32_t lightCount[4]; DirLight lights[5]; };
+struct PhysicalCamera { float widthPixel, heightPixel, focalLength, sensorWidth, focalDistance, fStop,
+                        x, y, z, wx, wy, wz; };
+
+static_assert(sizeof(BlobNode) == 48 && sizeof(BlobTri) == 16 && sizeof(BlobInst) == 80, "blob layout");
+static_assert(sizeof(Material) == 48 && sizeof(MeshInfo) == 32 && sizeof(SceneProperties) == 176 &&
+              sizeof(PhysicalCamera) == 48 && sizeof(RayTraceProperties) == 16, "host struct layout");
+
+// ---- derived device layout --------------------------------------------------------------------
+// stack / node references carry a 2-bit tag in the top bits
+enum : uint32_t { TAG_BLAS = 0u << 30, TAG_TLAS = 1u << 30, TAG_INST = 2u << 30, TAG_MASK = 3u << 30,
+                  IDX_MASK = ~(3u << 30) };
+
+struct alignas(16) DNode {        // 48 B; child / triangle indices are ABSOLUTE into the merged arrays
+    float bmin[4];
+    float bmax[4];
+    uint32_t w0, w1, w2, w3;      // as BlobNode
+};
+struct alignas(16) DTri {         // 48 B: v0, e1 = v1 - v0, e2 = v2 - v0 (single IEEE subtractions)
+    float v0[3]; uint32_t primID;
+    float e1[3]; uint32_t _p0;
+    float e2[3]; uint32_t _p1;
+};
+struct alignas(16) DInst {        // 160 B
+    float inv[16];                // InverseMat4x4(object->world), math.cl:56-183 evaluated once on the host
+    float fwd[16];                // object->world
+    uint32_t SBTOffset, instanceID, customInstanceID, blasRoot;   // blasRoot: absolute node index
+    uint32_t _pad[4];
+};
+
+} // namespace rdx

@@ -1,0 +1,292 @@
+// stages.h -- the SBT stage functions of the stock pipeline as HIP device code, and the SBT
+// dispatch generated from samples/sbt.json (tools/genSBT.py -> sbt_generated.h).
+//
+// Restates the *behaviour* of the reference's user shader and PBR library
+// (samples/shader.cl:308-605, radiance/shader/pbr.cl) for a wavefront tracer: the closest-hit
+// shader `material` traces its shadow ray in the middle of the function (shader.cl:499-509); here
+// it runs to completion and hands back both outcomes (lit / occluded) plus the shadow-ray origin,
+// and the any-hit traversal stage picks one afterwards.  Arithmetic per value is unchanged.
+#pragma once
+#include "device_math.h"
+#include "rdx_types.h"
+#include "sbt_generated.h"
+
+namespace rdx {
+
+#define RDX_PI 3.14159265359f   // pbr.cl:3
+
+struct SceneView {                  // descriptor slots 4-10 of the raygen kernel (shader.cl:175-190)
+    const SceneProperties* scene;
+    const MeshInfo* meshInfo;
+    const uint32_t* indexData;
+    const float* uvData;
+    const float* normalData;
+    const Material* materials;
+};
+
+struct HitInfo {                    // what struct HitData (radiance.cl:8-18) carries into a hit shader
+    f3 hitPoint;                    // object space
+    float bx, by, bz;               // barycentric (1-b1-b2, b1, b2)
+    uint32_t primitiveIndex, instanceIndex;
+    const float* fwd;               // object->world, row-major (DInst::fwd)
+};
+
+struct Payload {                    // struct Payload, shader.cl:4-13 (+ the deferred shadow query)
+    f3 color;                       // if the shadow ray is NOT occluded
+    f3 colorOccluded;               // if it is
+    f3 nextFactor, nextRayOrigin, nextRayDirection;
+    f3 shadowOrigin;
+    bool hit;
+    bool wantsShadowRay;
+};
+
+// ---------------------------------------------------------------------------------------------
+// pbr.cl
+// ---------------------------------------------------------------------------------------------
+__device__ inline void normal_space(f3 n, float* m)   // math.cl:269-298 GetNormalSpace
+{
+    float dd = 1.0f * n.x + 0.0f * n.y + 0.0f * n.z;
+    f3 tangent = mk3(0.0f, 1.0f, 0.0f);
+    if (1.0f - fabsf(dd) > 1e-6f) tangent = normalize3(cross3(mk3(1.0f, 0.0f, 0.0f), n));
+    f3 bitangent = cross3(n, tangent);
+    m[0] = tangent.x;   m[4] = tangent.y;   m[8] = tangent.z;    m[12] = 0.0f;
+    m[1] = bitangent.x; m[5] = bitangent.y; m[9] = bitangent.z;  m[13] = 0.0f;
+    m[2] = n.x;         m[6] = n.y;         m[10] = n.z;         m[14] = 0.0f;
+    m[3] = 0.0f;        m[7] = 0.0f;        m[11] = 0.0f;        m[15] = 1.0f;
+}
+
+__device__ inline float d_ggx(float dotNH, float roughness)   // pbr.cl:6-13
+{
+    float alpha = roughness * roughness;
+    float alpha2 = alpha * alpha;
+    float denom = dotNH * dotNH * (alpha2 - 1.0f) + 1.0f;
+    return alpha2 / (RDX_PI * denom * denom);
+}
+
+__device__ inline f3 f_schlick(float cosTheta, float metallic, f3 albedo)   // pbr.cl:31-37
+{
+    const f3 lo = mk3(0.04f, 0.04f, 0.04f);
+    f3 F0 = lo + (albedo - lo) * metallic;
+    float p = powf(1.0f - cosTheta, 5.0f);
+    return F0 + one_minus(F0) * p;
+}
+
+__device__ inline float smith_lambda(f3 w, float a)   // pbr.cl:41-74 Lambda and its trig helpers
+{
+    float cos2 = w.z * w.z;
+    float sin2 = fmaxf(0.0f, 1.0f - cos2);
+    float tan2 = sin2 / cos2;
+    if (isinf(tan2)) return 0.0f;
+    float sinT = sqrtf(sin2);
+    float cosPhi = (sinT == 0.0f) ? 1.0f : cl_clamp(w.x / sinT, -1.0f, 1.0f);
+    float sinPhi = (sinT == 0.0f) ? 0.0f : cl_clamp(w.y / sinT, -1.0f, 1.0f);
+    float alpha2 = (cosPhi * a) * (cosPhi * a) + (sinPhi * a) * (sinPhi * a);
+    return (sqrtf(1.0f + alpha2 * tan2) - 1.0f) / 2.0f;
+}
+
+__device__ inline float g_pbrt(f3 wo, f3 wi, f3 n, float roughness)   // pbr.cl:77-96
+{
+    float tbn[16], inv[16];
+    for (int i = 0; i < 16; ++i) inv[i] = 0.0f;   // reference: uninitialised if det == 0
+    normal_space(n, tbn);
+    inverse_mat4(tbn, inv);
+    f4 lo = mat4_mul(inv, wo.x, wo.y, wo.z, 0.0f);
+    f4 li = mat4_mul(inv, wi.x, wi.y, wi.z, 0.0f);
+    if (li.z < 0 || lo.z < 0) return 0.0f;
+    return 1 / (1 + smith_lambda(mk3(li.x, li.y, li.z), roughness) + smith_lambda(mk3(lo.x, lo.y, lo.z), roughness));
+}
+
+__device__ inline f3 reflect3(f3 in, f3 n) { return -in + n * (2 * dot3(in, n)); }   // pbr.cl:171-174
+
+__device__ inline f3 refract3(f3 V, f3 H, float eta)   // pbr.cl:176-186
+{
+    float ci = dot3(H, V);
+    float s2i = cl_max(0.0f, 1.0f - (ci * ci));
+    float s2t = s2i / (eta * eta);
+    if ((1.0f - s2t) < 0.0f) return (H * ci - V) / eta;
+    float ct = sqrtf(1.0f - s2t);
+    return (-V) / eta + H * (ci / eta - ct);
+}
+
+__device__ inline f3 microfacet_brdf(f3 L, f3 V, f3 N, f3 albedo, float metallic, float roughness, float transmission)
+{   // pbr.cl:268-287
+    f3 H = normalize3(V + L);
+    float NoV = cl_clamp(dot3(N, V), 0.0f, 1.0f);
+    float NoL = cl_clamp(dot3(N, L), 0.0f, 1.0f);
+    float NoH = cl_clamp(dot3(N, H), 0.0f, 1.0f);
+    float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
+    f3 F = f_schlick(VoH, metallic, albedo);
+    float D = d_ggx(NoH, roughness);
+    float G = g_pbrt(V, L, N, roughness);
+    f3 spec = (F * (D * G)) / cl_max(4.0f * NoV * NoL, 0.001f);
+    f3 notSpec = (one_minus(F) * (1.0f - metallic)) * (1.0f - transmission);
+    f3 diff = notSpec * (albedo / RDX_PI);
+    return (diff + spec) * NoL;
+}
+
+// local (theta, phi) direction rotated into the frame of `n`
+__device__ inline f3 frame_dir(f3 n, float theta, float phi)
+{
+    float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
+    float tbn[16];
+    normal_space(n, tbn);
+    return mat4_mul3(tbn, st * cp, st * sp, ct, 0.0f);
+}
+
+// pbr.cl:289-385 sampleMicrofacetBRDF_transm
+__device__ inline f3 sample_brdf_transm(f3 V, f3 N, f3 base, float metallic, float roughness, float transmission,
+                                        float ior, f3 rnd, f3& nextFactor)
+{
+    const float ggxTheta = acosf(sqrtf((1.0f - rnd.y) / (1.0f + ((roughness * roughness) * (roughness * roughness) - 1.0f) * rnd.y)));
+    const float phi = 2.0f * RDX_PI * rnd.x;
+    if (rnd.z < 0.5f) {
+        if ((2.0f * rnd.z) < transmission) {
+            f3 fn = N;
+            float eta = ior;
+            if (dot3(V, N) < 0.0f) { fn = -N; eta = 1.0f / ior; }
+            f3 H = frame_dir(fn, ggxTheta, phi);
+            f3 L = refract3(V, H, eta);
+            float NoV = cl_clamp(dot3(fn, V), 0.0f, 1.0f);
+            float NoH = cl_clamp(dot3(fn, H), 0.0f, 1.0f);
+            float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
+            f3 F = f_schlick(VoH, metallic, base);
+            float G = g_pbrt(V, -L, fn, roughness);
+            nextFactor = ((((base * one_minus(F)) * G) * VoH) / cl_max(NoH * NoV, 0.001f)) * 2.0f;
+            return L;
+        }
+        f3 L = frame_dir(N, acosf(sqrtf(rnd.y)), phi);
+        f3 H = normalize3(V + L);
+        float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
+        f3 F = f_schlick(VoH, metallic, base);
+        nextFactor = ((one_minus(F) * (1.0f - metallic)) * base) * 2.0f;
+        return L;
+    }
+    f3 H = frame_dir(N, ggxTheta, phi);
+    f3 L = reflect3(V, H);
+    float NoV = cl_clamp(dot3(N, V), 0.0f, 1.0f);
+    float NoH = cl_clamp(dot3(N, H), 0.0f, 1.0f);
+    float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
+    float G = g_pbrt(V, L, N, roughness);
+    f3 F = f_schlick(VoH, metallic, base);
+    nextFactor = (((F * G) * VoH) / cl_max(NoH * NoV, 0.001f)) * 2.0f;
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage functions named in samples/sbt.json
+// ---------------------------------------------------------------------------------------------
+
+// world-space hit position pushed off the surface along n (shader.cl:454-469)
+__device__ inline f3 offset_hit_position(const HitInfo& h, f3 n)
+{
+    f3 p = mat4_mul3(h.fwd, h.hitPoint.x, h.hitPoint.y, h.hitPoint.z, 1.0f);
+    return p + n * 0.00001f;
+}
+
+// closest-hit, SBT row 1 (shader.cl:482-541).  `sampleNext` = false on the last bounce, whose
+// sampled direction the raygen loop never uses.
+__device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s, f3 rayDir, uint32_t frameID,
+                                uint32_t pixel, uint32_t depth, bool sampleNext)
+{
+    p.hit = true;
+    const MeshInfo mi = s.meshInfo[h.instanceIndex];
+    const Material mt = s.materials[mi.materialIndex];
+    const uint32_t* ip = s.indexData + mi.indexOffset + h.primitiveIndex * 3;
+    const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+
+    // interpolated vertex normal -> world by the object->world matrix, w = 0 (shader.cl:340-368)
+    const float* nb = s.normalData + mi.normalOffset;
+    f3 n0 = mk3(nb[i0 * 3], nb[i0 * 3 + 1], nb[i0 * 3 + 2]);
+    f3 n1 = mk3(nb[i1 * 3], nb[i1 * 3 + 1], nb[i1 * 3 + 2]);
+    f3 n2 = mk3(nb[i2 * 3], nb[i2 * 3 + 1], nb[i2 * 3 + 2]);
+    f3 nl = mk3(h.bx * n0.x + h.by * n1.x + h.bz * n2.x, h.bx * n0.y + h.by * n1.y + h.bz * n2.y,
+                h.bx * n0.z + h.by * n1.z + h.bz * n2.z);
+    float nw = h.bx * 0.0f + h.by * 0.0f + h.bz * 0.0f;
+    f3 faceN = normalize3(mat4_mul3(h.fwd, nl.x, nl.y, nl.z, nw));
+    f3 hitPos = offset_hit_position(h, faceN);
+
+    // texture fetches are stubbed to 0 in the live reference shader (shader.cl:379,411,421,445)
+    f3 N = faceN;
+    if (mt.normalTexIdx != -1) {
+        f4 t; t.x = cl_clamp(0.0f / 255.0f, 0.0f, 1.0f) * 2.0f - 1.0f; t.y = t.x; t.z = t.x; t.w = 0.0f * 2.0f - 1.0f;
+        t = normalize4(t);
+        float tbn[16];
+        normal_space(faceN, tbn);
+        N = normalize3(mat4_mul3(tbn, t.x, t.y, t.z, t.w));
+    }
+    const float* ld = s.scene->lights[0].direction;
+    f3 L = normalize3(mk3(-ld[0], -ld[1], -ld[2]));
+    f3 V = normalize3(-rayDir);
+
+    float metallic = (mt.metallicTexIdx == -1) ? mt.metallic : cl_clamp(0.0f / 255.0f, 0.0f, 1.0f);
+    float roughness = (mt.roughnessTexIdx == -1) ? cl_clamp(mt.roughness, 0.0f, 1.0f) : cl_clamp(0.0f / 255.0f, 0.05f, 1.0f);
+    float transmission = cl_clamp(mt.transmission, 0.0f, 1.0f);
+    float ior = cl_clamp(mt.ior, 0.0f, 10.0f);
+    f3 albedo = (mt.albedoTexIdx == -1) ? mk3(mt.albedo[0], mt.albedo[1], mt.albedo[2])
+                                        : mk3(cl_clamp(0.0f / 255.0f, 0.0f, 1.0f), cl_clamp(0.0f / 255.0f, 0.0f, 1.0f), cl_clamp(0.0f / 255.0f, 0.0f, 1.0f));
+
+    // deferred shadow query: traceRay(topLevel, 2, 4, hitPos, L, 0.001, 1000) (shader.cl:499-501)
+    p.wantsShadowRay = true;
+    p.shadowOrigin = hitPos;
+    const float* lc = s.scene->lights[0].color;
+    f3 direct = mk3(0.0f, 0.0f, 0.0f) + microfacet_brdf(L, V, N, albedo, metallic, roughness, transmission) * mk3(lc[0], lc[1], lc[2]);
+    f3 ambient = albedo * 0.1f;
+    p.color = direct + ambient;
+    p.colorOccluded = mk3(0.0f, 0.0f, 0.0f) + ambient;
+
+    if (sampleNext) {
+        f3 rnd = pcg3d(frameID, pixel, depth);
+        f3 nf = mk3(0.0f, 0.0f, 0.0f);
+        f3 nd = sample_brdf_transm(V, N, albedo, metallic, roughness, transmission, ior, rnd, nf);
+        if (dot3(nd, N) < 0) hitPos = offset_hit_position(h, -faceN);
+        p.nextRayOrigin = hitPos;
+        p.nextRayDirection = nd;
+        p.nextFactor = nf;
+    }
+}
+
+// closest-hit, SBT row 2 (shader.cl:559-565)
+__device__ inline void shadow(Payload& p, const HitInfo&, const SceneView&, f3, uint32_t, uint32_t, uint32_t, bool)
+{
+    p.hit = true;
+    p.color = mk3(0.0f, 0.0f, 0.0f);
+    p.colorOccluded = p.color;
+}
+// any-hit, SBT row 2 (shader.cl:567-572)
+__device__ inline void anyShadow(bool& cont) { cont = false; }
+// miss, SBT rows 3 and 4 (shader.cl:543-557)
+__device__ inline void environment(Payload& p) { p.hit = false; p.color = mk3(0.2f, 0.2f, 0.5f); p.colorOccluded = p.color; }
+__device__ inline void shadowMiss(Payload& p) { p.hit = false; p.color = mk3(1.0f, 1.0f, 1.0f); p.colorOccluded = p.color; }
+
+// ---- SBT dispatch, expanded from the generated tables (the reference keeps these switches by hand
+//      in shader.cl:574-605; index = instanceSBTOffset + sbtRecordOffset, or missIndex) -----------
+__device__ inline void callHit(int index, Payload& p, const HitInfo& h, const SceneView& s, f3 rayDir,
+                               uint32_t frameID, uint32_t pixel, uint32_t depth, bool sampleNext)
+{
+    switch (index) {
+#define X(row, fn) case row: fn(p, h, s, rayDir, frameID, pixel, depth, sampleNext); break;
+        RDX_SBT_CLOSEST_HIT(X)
+#undef X
+    default: break;
+    }
+}
+__device__ inline void callAnyHit(bool& cont, int index)
+{
+    switch (index) {
+#define X(row, fn) case row: fn(cont); break;
+        RDX_SBT_ANY_HIT(X)
+#undef X
+    default: break;
+    }
+}
+__device__ inline void callMiss(int index, Payload& p)
+{
+    switch (index) {
+#define X(row, fn) case row: fn(p); break;
+        RDX_SBT_MISS(X)
+#undef X
+    default: break;
+    }
+}
+
+} // namespace rdx

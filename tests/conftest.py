@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """librdx.so + liboracle.so present (builds them when a compiler is around)."""
+    import __graft_entry__ as ge
+    ge.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    import rrt_amd
+    from radiance_ray_tracing_amd import rd
+    return rd.Platform.GetPlatform()

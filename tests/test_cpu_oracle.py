@@ -1,0 +1,222 @@
+"""CPU suite (-m "not gpu"): the oracle against the golden vectors, the host logic (BVH builder,
+blob packers, SBT generator) and the C-ABI surface.  No compute call touches a GPU here."""
+import ctypes
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def pkg(built):
+    import rrt_amd
+    return rrt_amd.pkg
+
+
+# ---- real-reference pins ------------------------------------------------------------------------
+def test_oracle_matches_reference_kat():
+    """oracle == outputs of the reference's own builtin-free device functions (tests/golden/ref_kat.npz)"""
+    g = {k: np.ascontiguousarray(v) for k, v in np.load(os.path.join(GOLD, "ref_kat.npz")).items()}
+    L = ob.lib()
+    out = ob.pcg3d(g["pcg_in"])
+    assert np.array_equal(out.view(np.uint32), g["pcg_out"].view(np.uint32))
+    mats, vecs = g["mats"], g["vecs"]
+    for k in range(mats.shape[0]):
+        m, v = mats[k].copy(), vecs[k].copy()
+        inv = np.zeros(16, np.float32)
+        ok = L.orc_inverse_mat4(m.ctypes.data, inv.ctypes.data)
+        assert ok == g["inv_ok"][k]
+        if ok:
+            assert np.array_equal(inv.view(np.uint32), g["inv_out"][k].view(np.uint32)), k
+        mv = np.zeros(4, np.float32)
+        L.orc_mul_mat4_vec4(m.ctypes.data, v.ctypes.data, mv.ctypes.data)
+        assert np.array_equal(mv.view(np.uint32), g["mv_out"][k].view(np.uint32)), k
+    gg = np.array([L.orc_d_ggx(float(a), float(b)) for a, b in g["gg_in"]], np.float32)
+    assert np.array_equal(gg.view(np.uint32), g["gg_out"].view(np.uint32))
+
+
+def test_oracle_matches_live_reference_if_present():
+    """same check against oracle/_ref executed live (only in the build container)"""
+    R = ob.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built here")
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 2**32, size=(4096, 3), dtype=np.uint64).astype(np.uint32)
+    a = ob.pcg3d(x)
+    b = np.zeros_like(a)
+    R.ref_pcg3d(x.ctypes.data, b.ctypes.data, x.shape[0])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    m = rng.normal(size=(256, 16)).astype(np.float32)
+    for k in range(256):
+        i0 = np.zeros(16, np.float32); i1 = np.zeros(16, np.float32)
+        row = m[k].copy()
+        assert ob.lib().orc_inverse_mat4(row.ctypes.data, i0.ctypes.data) == R.ref_inverse_mat4(row.ctypes.data, i1.ctypes.data)
+        assert np.array_equal(i0.view(np.uint32), i1.view(np.uint32))
+
+
+def test_gensbt_row_mapping_matches_reference_generator(pkg):
+    """row index -> shader name of tools/genSBT.py == what the reference's own generator printed for
+    its samples/sbt.json (tests/golden/ref_gensbt.txt), plus the any-hit table the reference forgot."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import importlib
+    gen = importlib.import_module("genSBT")
+    rows = gen.sbt_rows(gen.read_json_file(os.path.join(ROOT, "samples", "sbt.json")))
+    ref_hit, ref_miss = {}, {}
+    for line in open(os.path.join(GOLD, "ref_gensbt.txt")):
+        m = re.match(r"\s*case (\d+):(\w+)\((.*)\);break;", line)
+        if m:
+            (ref_hit if "hitData" in m.group(3) else ref_miss)[int(m.group(1))] = m.group(2)
+    assert dict(rows["closestHit"]) == ref_hit == {1: "material", 2: "shadow"}
+    assert dict(rows["miss"]) == ref_miss == {3: "environment", 4: "shadowMiss"}
+    assert dict(rows["anyHit"]) == {2: "anyShadow"} and dict(rows["raygen"]) == {0: "raygen"}
+    # the committed generated header is up to date
+    hdr = open(os.path.join(ROOT, "radiance-ray-tracing_amd", "csrc", "sbt_generated.h")).read()
+    assert hdr == gen.generate(gen.read_json_file(os.path.join(ROOT, "samples", "sbt.json")))
+
+
+# ---- oracle self-goldens --------------------------------------------------------------------------
+def test_oracle_self_goldens(pkg):
+    from radiance_ray_tracing_amd import scenes
+    g = np.load(os.path.join(GOLD, "oracle_kat.npz"))
+    for name, fn, kw in (("c0", scenes.c0_two_boxes, dict(width=32, height=32, spp=2, depth=3)),
+                         ("c1", scenes.c1_cornell, dict(width=32, height=18, spp=2, depth=4, sphere_subdiv=2))):
+        s = fn(**kw)
+        blob, _, _ = ob.scene_tlas(s)
+        assert hashlib.sha256(blob).digest() == g[name + "_blob_sha256"].tobytes()
+        hits = ob.trace_batch(blob, g[name + "_ray_o"], g[name + "_ray_d"])
+        assert np.array_equal(hits.view(np.uint8).reshape(hits.shape[0], -1), g[name + "_hits"])
+        sh = ob.trace_batch(blob, g[name + "_ray_o"], g[name + "_ray_d"], sbtRecordOffset=2)
+        assert np.array_equal(sh["hit"].astype(np.uint8), g[name + "_shadow_hit"])
+        osc = ob.OracleScene(s, blob)
+        osc.frame(); osc.frame()
+        assert np.allclose(osc.scratch, g[name + "_scratch"], rtol=0, atol=1e-6)
+        assert np.abs(osc.image.astype(int) - g[name + "_image"].astype(int)).max() <= 1
+
+
+def test_struct_sizes():
+    """sizeof of every struct crossing the boundary"""
+    out = np.zeros(12, np.uint32)
+    ob.lib().orc_struct_sizes(out.ctypes.data, 12)
+    assert list(out) == [48, 16, 16, 80, 16, 16, 48, 32, 32, 176, 48, 16]
+
+
+def test_slab_and_triangle_edge_cases():
+    L = ob.lib()
+    f = lambda *a: np.array(a, np.float32)
+    # a perfectly flat box can never pass `tFar > max(tNear, 0)` (reference quirk, radiance.cl:195-208)
+    assert L.orc_intersect_aabb(f(0, 1, 0).ctypes.data, f(0, -1, 0).ctypes.data, f(-1, 0, -1).ctypes.data, f(1, 0, 1).ctypes.data) == 0
+    assert L.orc_intersect_aabb(f(0, 1, 0).ctypes.data, f(0.1, -1, 0.1).ctypes.data, f(-1, -0.5, -1).ctypes.data, f(1, 0, 1).ctypes.data) == 1
+    # box entirely behind the origin
+    assert L.orc_intersect_aabb(f(0, 0, 5).ctypes.data, f(0, 0, 1).ctypes.data, f(-1, -1, -1).ctypes.data, f(1, 1, 1).ctypes.data) == 0
+    t = np.zeros(1, np.float32); p = np.zeros(3, np.float32); b = np.zeros(3, np.float32)
+    args = (f(0.25, 0.25, 1), f(0, 0, -1), f(0, 0, 0), f(1, 0, 0), f(0, 1, 0))
+    assert L.orc_intersect_triangle(*[a.ctypes.data for a in args], t.ctypes.data, p.ctypes.data, b.ctypes.data) == 1
+    assert t[0] == 1.0 and np.allclose(b, [0.5, 0.25, 0.25])
+    # no back-face culling; parallel ray rejected only when det == 0 exactly
+    args = (f(0.25, 0.25, -1), f(0, 0, 1), f(0, 0, 0), f(1, 0, 0), f(0, 1, 0))
+    assert L.orc_intersect_triangle(*[a.ctypes.data for a in args], t.ctypes.data, p.ctypes.data, b.ctypes.data) == 1
+    args = (f(0.25, 0.25, 1), f(1, 0, 0), f(0, 0, 0), f(1, 0, 0), f(0, 1, 0))
+    assert L.orc_intersect_triangle(*[a.ctypes.data for a in args], t.ctypes.data, p.ctypes.data, b.ctypes.data) == 0
+
+
+# ---- host logic of the product: BVH builder + blob packers vs the oracle's naive restatement ---------
+@pytest.mark.parametrize("case", ["one_triangle", "cube", "c0", "c1_small", "shared_blas", "c2_small", "signed_zero"])
+def test_builder_blobs_bit_exact(pkg, case):
+    from radiance_ray_tracing_amd import rd, scenes
+    if case == "one_triangle":
+        s = scenes.Scene("tri")
+        s.add_instance(s.add_mesh(scenes._finish(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), [[0, 1, 2]], np.array([[0, 0, 1]] * 3))), None, 0)
+    elif case == "cube":
+        s = scenes.Scene("cube")
+        s.add_instance(s.add_mesh(scenes.box([-1, -2, -3], [1, 2, 3])), scenes.translate(1, 2, 3) @ scenes.rotate_y(33), 0)
+    elif case == "c0":
+        s = scenes.c0_two_boxes(32, 32)
+    elif case == "c1_small":
+        s = scenes.c1_cornell(32, 18, sphere_subdiv=3)
+    elif case == "shared_blas":          # 9-instance grid sharing two BLAS (dedup path, bvh.cpp:575-588)
+        s = scenes.Scene("grid")
+        a = s.add_mesh(scenes.icosphere(2, 0.5)); b = s.add_mesh(scenes.box([-.4, -.4, -.4], [.4, .4, .4]))
+        for k in range(9):
+            s.add_instance(a if k % 2 else b, scenes.translate(1.5 * (k % 3), 0.3 * k, 1.5 * (k // 3)) @ scenes.rotate_y(10 * k), k)
+    elif case == "c2_small":
+        s = scenes.c2_atrium(32, 18, detail=0.2)
+    else:                                   # mixed +0 / -0 coordinates keep their sign through every min/max
+        v = np.array([[0.0, 0, 0], [-0.0, 1, 0], [1, -0.0, 0], [1, 1, -0.0]] * 4, np.float32)
+        v[4:] += np.arange(12, dtype=np.float32)[:, None] * 0.25
+        t = np.array([[0, 1, 2], [1, 2, 3], [4, 5, 6], [5, 6, 7], [8, 9, 10], [9, 10, 11], [12, 13, 14], [13, 14, 15],
+                      [0, 5, 10], [3, 6, 9]], np.uint32)
+        s = scenes.Scene("zeros")
+        s.meshes.append((v, t, np.zeros_like(v), np.zeros_like(v)))
+        s.add_instance(0, None, 0)
+    blob_o, depth_o, blases_o = ob.scene_tlas(s)
+    blas_p = [rd.BuildAccelStruct(None, rd.Mesh(m[0], m[1])) for m in s.meshes]
+    for bo, bp in zip(blases_o, blas_p):
+        assert bo.blob == bp.data
+        assert bo.max_depth == bp.max_depth
+    insts = [rd.Instance(tf, 0, mat, blas_p[mi]) for (mi, tf, mat) in s.instances]
+    blob_p, depth_p = rd.BuildTopAccelStructBlob(insts)
+    assert blob_o == blob_p and depth_o == depth_p
+    # header invariants of the blob layout (data.cl:237-278)
+    hdr = np.frombuffer(blob_p[:16], np.uint32)
+    assert hdr[0] == 1 and hdr[1] == 16 and hdr[3] == len(blob_p)
+
+
+def test_builder_rejects_bad_input(pkg):
+    from radiance_ray_tracing_amd import rd
+    with pytest.raises(rd.RadianceError):
+        rd.BuildAccelStruct(None, rd.Mesh(np.zeros((3, 3), np.float32), np.array([[0, 1, 7]], np.uint32)))
+    with pytest.raises(rd.RadianceError):
+        rd.BuildAccelStruct(None, rd.Mesh())
+    with pytest.raises(rd.RadianceError):
+        rd.BuildTopAccelStructBlob([])
+
+
+# ---- C ABI ---------------------------------------------------------------------------------------------
+def test_cabi_exports_every_declared_symbol(pkg):
+    """librdx.so loads and exports exactly the functions include/rdx.h declares (no compute calls)"""
+    from radiance_ray_tracing_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "rdx.h")).read()
+    declared = set(re.findall(r"\b(rdx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (rdx_[a-z0-9_]+)", out))
+    assert declared <= exported
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    """without a device the product fails loudly instead of falling back to any CPU path"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from radiance_ray_tracing_amd import rd, _lib
+    rd.Platform._instance = None
+    with pytest.raises(rd.RadianceError) as e:
+        rd.Platform.GetPlatform()
+    assert "no HIP device" in str(e.value) or "HIP" in str(e.value)
+    assert _lib.lib().rdx_buffer_create(16) is None
+
+
+def test_product_never_touches_the_oracle():
+    """nothing under radiance-ray-tracing_amd/ or include/ references oracle/ or liboracle"""
+    bad = []
+    for base in ("radiance-ray-tracing_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".cpp", ".h", ".hip")):
+                    txt = open(os.path.join(dp, f), errors="replace").read()
+                    if re.search(r"liboracle|oracle_bind|orc_[a-z]+\(|oracle/", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,331 @@
+"""GPU parity suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Integer / index work (RNG, hit primitive and instance ids, visit counters) and
+everything built from + - * / sqrt (t, barycentrics, hit points, pinhole rays) must be BIT-EXACT;
+shading and frames go through sin/cos/acos/pow (glibc vs OCML), tolerance stated per test."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_bind as ob
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def mods(gpu):
+    import rrt_amd
+    from radiance_ray_tracing_amd import rd, scenes
+    return rd, scenes
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint8)
+
+
+def _small_scenes(scenes):
+    return {
+        "c0": scenes.c0_two_boxes(64, 64, spp=2, depth=3),
+        "c1": scenes.c1_cornell(96, 54, spp=2, depth=4, sphere_subdiv=3),
+        "c2": scenes.c2_atrium(96, 54, spp=2, depth=4, detail=0.2),
+    }
+
+
+def _ray_batch(osc, n, seed):
+    """primary rays + scattered secondaries + axis-aligned / grazing / on-surface rays"""
+    rng = np.random.default_rng(seed)
+    s = osc.scene
+    px = rng.integers(0, s.width * s.height, n).astype(np.uint32)
+    rin = np.stack([rng.integers(0, 8, n).astype(np.uint32), np.zeros(n, np.uint32), px], 1)
+    o, d = osc.generate_rays(px, rin)
+    hits = ob.trace_batch(osc.tlas.tobytes(), o, d)
+    # secondaries: start at the world-space hit point of the primaries, random directions
+    hp = o + d * hits["distance"][:, None]
+    ok = hits["hit"] == 1
+    d2 = rng.normal(size=(n, 3)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    o2 = np.where(ok[:, None], hp, o).astype(np.float32)
+    # axis-aligned and grazing directions (zeros in the direction exercise the inf / NaN slab paths)
+    d3 = np.zeros((n, 3), np.float32)
+    d3[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+    o3 = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    d4 = d2.copy(); d4[:, 1] *= 1e-4
+    return (np.concatenate([o, o2, o3, o2]).astype(np.float32), np.concatenate([d, d2, d3, d4]).astype(np.float32))
+
+
+def test_pcg3d_bit_exact(mods):
+    rd, _ = mods
+    g = np.load(os.path.join(GOLD, "ref_kat.npz"))
+    out = rd.Pcg3dBatch(g["pcg_in"])
+    assert np.array_equal(_bits(out), _bits(g["pcg_out"]))          # vs the real reference function
+    x = np.random.default_rng(1).integers(0, 2**32, size=(100000, 3), dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(_bits(rd.Pcg3dBatch(x)), _bits(ob.pcg3d(x)))
+
+
+@pytest.mark.parametrize("name", ["c0", "c1", "c2"])
+def test_traversal_bit_exact(mods, name):
+    """closest-hit and any-hit HitData (t, bary, hit point, primitive / instance ids, transform) are
+    bit-identical to the oracle, and so are the visit counters of the exhaustive walk"""
+    rd, scenes = mods
+    s = _small_scenes(scenes)[name]
+    dev = scenes.DeviceScene(s)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    blob_o, _, _ = ob.scene_tlas(s)
+    assert blob == blob_o                                            # device blob == oracle blob
+    osc = ob.OracleScene(s, blob_o)
+    o, d = _ray_batch(osc, 4096, 5)
+    for rec in (1, 2):
+        ref, ctr = ob.trace_batch(blob_o, o, d, 0.001, 1000.0, rec, counters=True)
+        got, visit = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, count_visits=True)
+        assert np.array_equal(ref["hit"], got["hit"])
+        h = ref["hit"] == 1
+        for f in ("distance", "primitiveIndex", "instanceIndex", "instanceCustomIndex", "instanceSBTOffset",
+                  "barycentric", "hitPoint", "transform"):
+            assert np.array_equal(_bits(ref[f][h]), _bits(got[f][h])), (rec, f)
+        c = ctr.as_dict()
+        assert list(visit) == [c["top_nodes"][rec - 1], c["inst_visits"][rec - 1], c["bot_nodes"][rec - 1], c["tri_tests"][rec - 1]]
+    assert h.sum() > 500      # the batch really exercises hits
+
+
+def test_traversal_matches_committed_golden(mods):
+    rd, scenes = mods
+    g = np.load(os.path.join(GOLD, "oracle_kat.npz"))
+    for name, fn, kw in (("c0", scenes.c0_two_boxes, dict(width=32, height=32, spp=2, depth=3)),
+                         ("c1", scenes.c1_cornell, dict(width=32, height=18, spp=2, depth=4, sphere_subdiv=2))):
+        dev = scenes.DeviceScene(fn(**kw))
+        got = rd.TraceBatch(dev.topAccelStruct, g[name + "_ray_o"], g[name + "_ray_d"])
+        assert np.array_equal(_bits(got).reshape(got.shape[0], -1), g[name + "_hits"])
+        sh = rd.TraceBatch(dev.topAccelStruct, g[name + "_ray_o"], g[name + "_ray_d"], sbtRecordOffset=2)
+        assert np.array_equal(sh["hit"].astype(np.uint8), g[name + "_shadow_hit"])
+
+
+def test_primary_rays(mods):
+    """pinhole rays are + - * / sqrt only (rotation constants come from the host) -> bit-exact;
+    the thin-lens path adds sin/cos of the disk sample -> 1e-6"""
+    rd, scenes = mods
+    for fstop, exact in ((0.0, True), (2.8, False)):
+        s = scenes.c1_cornell(96, 54, sphere_subdiv=1, fstop=fstop)
+        dev = scenes.DeviceScene(s)
+        osc = ob.OracleScene(s)
+        rng = np.random.default_rng(2)
+        px = rng.integers(0, 96 * 54, 5000).astype(np.uint32)
+        rin = rng.integers(0, 2**32, size=(5000, 3), dtype=np.uint64).astype(np.uint32)
+        o, d = osc.generate_rays(px, rin)
+        go, gd = rd.GenerateBatch(px, rin)
+        if exact:
+            assert np.array_equal(_bits(o), _bits(go)) and np.array_equal(_bits(d), _bits(gd))
+        else:
+            assert np.abs(o - go).max() < 1e-6 and np.abs(d - gd).max() < 1e-6
+
+
+def test_material_shading(mods):
+    """closest-hit `material` on captured hits (diffuse, metal, glass): float tolerance 2e-5 relative
+    to the value scale (transcendentals differ between glibc and OCML by ulps)"""
+    rd, scenes = mods
+    s = scenes.c1_cornell(96, 54, sphere_subdiv=3)
+    dev = scenes.DeviceScene(s)
+    osc = ob.OracleScene(s)
+    rng = np.random.default_rng(9)
+    n = 6000
+    px = rng.integers(0, 96 * 54, n).astype(np.uint32)
+    rin = np.stack([np.zeros(n, np.uint32), np.zeros(n, np.uint32), px], 1)
+    o, d = osc.generate_rays(px, rin)
+    hits = ob.trace_batch(osc.tlas.tobytes(), o, d)
+    k = hits["hit"] == 1
+    hits, d, px = hits[k], d[k], px[k]
+    frames = rng.integers(0, 64, hits.shape[0]).astype(np.uint32)
+    depths = rng.integers(0, 8, hits.shape[0]).astype(np.int32)
+    ref = osc.material_batch(hits, d, px, frames, depths)
+    got = rd.MaterialBatch(hits, d, px, frames, depths)
+    assert np.array_equal(ref["hit"], got["hit"])
+    for f in ("nextFactor", "nextRayOrigin", "nextRayDirection"):
+        scale = np.maximum(1.0, np.abs(ref[f]))
+        assert (np.abs(ref[f] - got[f]) / scale).max() < 2e-5, f
+    # the oracle's colour includes its shadow test; the GPU seam reports the light-visible outcome.
+    # So the oracle colour is either that (tolerance) or exactly the ambient term albedo * 0.1.
+    albedo = np.array(s.materials)["albedo"][hits["instanceCustomIndex"], :3]
+    ambient = (albedo * np.float32(0.1)).astype(np.float32)
+    rel = np.abs(ref["color"] - got["color"]) / np.maximum(1.0, np.abs(ref["color"]))
+    lit = np.all(rel < 2e-5, axis=1)
+    occluded = np.all(ref["color"] == ambient, axis=1)
+    assert np.all(lit | occluded)
+    assert lit.sum() > 100 and occluded.sum() > 100
+    assert set(np.unique(hits["instanceCustomIndex"])) >= {0, 3, 4}      # diffuse, metal and glass were hit
+
+
+@pytest.mark.parametrize("name", ["c0", "c1", "c2"])
+def test_frame_radiance_rmse(mods, name):
+    """whole frames: imageScratch RMSE < 1e-4 (north-star tolerance), RGBA8 within 1 LSB on >= 99.9 %
+    of the bytes; second TraceRays call exercises the progressive running mean (totalSamples > 0)"""
+    rd, scenes = mods
+    s = _small_scenes(scenes)[name]
+    dev = scenes.DeviceScene(s)
+    osc = ob.OracleScene(s)
+    for frame in range(2):
+        img = dev.render()
+        osc.frame()
+        got = dev.read_scratch().reshape(-1).astype(np.float64)
+        ref = osc.scratch.astype(np.float64)
+        rmse = np.sqrt(np.mean((got - ref) ** 2))
+        assert rmse < 1e-4, (name, frame, rmse)
+        diff = np.abs(img.reshape(-1).astype(int) - osc.image.astype(int))
+        assert (diff <= 1).mean() >= 0.999
+        st = rd.GetTraceStats()
+        assert st.rays_primary == s.width * s.height * int(s.rtprop["batchSize"])
+
+
+def test_ray_counts_match_oracle(mods):
+    """rays actually traced == the reference algorithm's traceRay count minus the one duplicate
+    re-trace the reference issues after each primary miss (shader.cl:243-252 does not break at
+    depth 0, the re-trace misses again and ends the path)"""
+    rd, scenes = mods
+    s = scenes.c0_two_boxes(64, 64, spp=1, depth=3)
+    dev = scenes.DeviceScene(s)
+    dev.render()
+    st = rd.GetTraceStats()
+    osc = ob.OracleScene(s)
+    c = osc.render(counters=True).as_dict()
+    px = np.arange(64 * 64, dtype=np.uint32)
+    o, d = osc.generate_rays(px, np.stack([np.zeros_like(px), np.zeros_like(px), px], 1))
+    primary_misses = int((ob.trace_batch(osc.tlas.tobytes(), o, d)["hit"] == 0).sum())
+    assert st.rays_primary == c["primary"] == 64 * 64
+    assert st.rays_shadow == c["shadow"] == c["rays"][1] == c["hits"] == st.closest_hits
+    assert c["rays"][0] == c["primary"] + c["bounce"]
+    assert st.rays_bounce + primary_misses == c["bounce"]
+
+
+def test_debug_and_degenerate_rtprops(mods):
+    rd, scenes = mods
+    s = scenes.c0_two_boxes(48, 48, spp=2, depth=4)
+    dev = scenes.DeviceScene(s)
+    osc = ob.OracleScene(s)
+    for kw in (dict(debug=1), dict(debug=0, depth=0), dict(depth=1, batchSize=1), dict(batchSize=0, depth=3)):
+        dev.set_rtprop(totalSamples=0, **kw); osc.set_rtprop(totalSamples=0, **kw)
+        dev.clear_scratch(); osc.scratch[:] = 0
+        img = dev.render(); osc.frame()
+        assert np.sqrt(np.mean((dev.read_scratch().reshape(-1) - osc.scratch) ** 2)) < 1e-5, kw
+        assert (np.abs(img.reshape(-1).astype(int) - osc.image.astype(int)) <= 1).mean() >= 0.999, kw
+
+
+def test_chunked_samples_identical(mods):
+    """splitting a batch into sample chunks (bounded paths in flight) does not change a single bit"""
+    rd, scenes = mods
+    s = scenes.c1_cornell(64, 36, spp=4, depth=4, sphere_subdiv=2)
+    dev = scenes.DeviceScene(s)
+    dev.render()
+    a = dev.read_scratch().copy()
+    rd.SetOption("chunk_paths", 64 * 36)        # one sample per chunk
+    try:
+        dev.set_rtprop(totalSamples=0)
+        dev.clear_scratch()
+        dev.render()
+        b = dev.read_scratch().copy()
+    finally:
+        rd.SetOption("chunk_paths", 16 << 20)
+    assert np.array_equal(_bits(a), _bits(b))
+
+
+def test_tile_sharding_bit_identical(mods):
+    """rendering rank r of w ranks in turn and merging == the unsharded frame, bit for bit
+    (pixel / RNG indices stay global); pack -> unpack of the owned tiles round-trips"""
+    rd, scenes = mods
+    s = scenes.c1_cornell(100, 60, spp=2, depth=3, sphere_subdiv=2)      # not a multiple of the tile size
+    dev = scenes.DeviceScene(s)
+    dev.render()
+    full = dev.read_scratch().copy()
+    full_img = rd.ReadBuffer(dev.plt, dev.rdImage, 100 * 60 * 4).copy()
+    W, H, world = 100, 60, 3
+    merged = rd.CreateBuffer(dev.plt, W * H * 16)
+    merged_img = rd.CreateBuffer(dev.plt, W * H * 4)
+    try:
+        for r in range(world):
+            rd.SetShard(r, world, 16, 16)
+            dev.set_rtprop(totalSamples=0)
+            dev.clear_scratch()
+            dev.render()
+            from radiance_ray_tracing_amd import _lib
+            L = _lib.lib()
+            ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+            owned = (ntiles - r + world - 1) // world
+            packed = rd.CreateBuffer(dev.plt, owned * 256 * 16)
+            packed8 = rd.CreateBuffer(dev.plt, owned * 256 * 4)
+            assert L.rdx_pack_tiles(dev.rdImageScratch.handle, packed.handle, W, H, 16, r, world) == 0
+            assert L.rdx_unpack_tiles(packed.handle, merged.handle, W, H, 16, r, world) == 0
+            assert L.rdx_pack_tiles(dev.rdImage.handle, packed8.handle, W, H, 4, r, world) == 0
+            assert L.rdx_unpack_tiles(packed8.handle, merged_img.handle, W, H, 4, r, world) == 0
+    finally:
+        rd.SetShard(0, 1, 64, 64)
+    got = np.empty(W * H * 4, np.float32)
+    rd.ReadBuffer(dev.plt, merged, got.nbytes, got.view(np.uint8))
+    assert np.array_equal(_bits(got[np.arange(W * H * 4) % 4 != 3]), _bits(full.reshape(-1)[np.arange(W * H * 4) % 4 != 3]))
+    assert np.array_equal(rd.ReadBuffer(dev.plt, merged_img, W * H * 4), full_img)
+
+
+def test_tlas_cache_file_roundtrip(mods, tmp_path):
+    """TopAccelStructToFile / FileToTopAccelStruct (radiance.cpp:428-479): raw blob, byte-identical,
+    and the reloaded structure traces identically"""
+    rd, scenes = mods
+    s = scenes.c1_cornell(32, 18, sphere_subdiv=2)
+    dev = scenes.DeviceScene(s)
+    path = str(tmp_path / "scene.cache")
+    rd.TopAccelStructToFile(dev.plt, dev.topAccelStruct, path)
+    blob_o, _, _ = ob.scene_tlas(s)
+    assert open(path, "rb").read() == blob_o
+    tl = rd.FileToTopAccelStruct(dev.plt, path)
+    osc = ob.OracleScene(s, blob_o)
+    o, d = _ray_batch(osc, 512, 3)
+    assert np.array_equal(_bits(rd.TraceBatch(tl, o, d)), _bits(rd.TraceBatch(dev.topAccelStruct, o, d)))
+    with pytest.raises(rd.RadianceError):
+        rd.FileToTopAccelStruct(dev.plt, str(tmp_path / "missing.cache"))
+    open(str(tmp_path / "short.cache"), "wb").write(blob_o[:100])
+    with pytest.raises(rd.RadianceError):
+        rd.FileToTopAccelStruct(dev.plt, str(tmp_path / "short.cache"))
+
+
+def test_error_paths(mods):
+    rd, scenes = mods
+    plt = rd.Platform.GetPlatform()
+    b = rd.CreateBuffer(plt, 64)
+    with pytest.raises(rd.RadianceError):
+        rd.WriteBuffer(plt, b, 128, np.zeros(128, np.uint8))
+    with pytest.raises(rd.RadianceError):
+        rd.ReadBuffer(plt, b, 32, np.zeros(32, np.uint8), offset=48)
+    with pytest.raises(rd.RadianceError):
+        rd.CreateShaderModule(plt, "void main() {}", 14, "x")         # no raygen kernel
+    s = scenes.c0_two_boxes(16, 16)
+    dev = scenes.DeviceScene(s)
+    with pytest.raises(rd.RadianceError):
+        rd.TraceRays(plt, 0, 0, 0, 64, 64)                            # buffers sized for 16x16
+    # a non-TLAS buffer in slot 13 is rejected
+    ds = list(dev.descSet); ds[13] = dev.rdCamData
+    rd.BindDescriptorSet(plt, ds)
+    with pytest.raises(rd.RadianceError):
+        rd.TraceRays(plt, 0, 0, 0, 16, 16)
+    dev.bind()
+    rd.TraceRays(plt, 0, 0, 0, 16, 16)
+
+
+def test_full_size_properties(mods):
+    """BASELINE config 1 at full size (1920x1080, 4 spp, depth 8): size-independent properties --
+    determinism (two runs bit-identical), progressive mean (frame 2 = exact running mean of two
+    independent batches), shadow rays == closest hits, finite radiance, and a 4096-pixel random
+    subset re-rendered by the oracle agrees to RMSE < 1e-4"""
+    rd, scenes = mods
+    s = scenes.c1_cornell()
+    dev = scenes.DeviceScene(s)
+    dev.render()
+    a = dev.read_scratch().copy()
+    st = rd.GetTraceStats()
+    assert st.rays_primary == 1920 * 1080 * 4 and st.rays_shadow == st.closest_hits
+    assert np.isfinite(a).all()
+    dev.set_rtprop(totalSamples=0); dev.clear_scratch()
+    dev.render()
+    assert np.array_equal(_bits(a), _bits(dev.read_scratch()))
+    # oracle on a pixel subset of the same frame
+    osc = ob.OracleScene(s)
+    px = np.random.default_rng(4).choice(1920 * 1080, 4096, replace=False).astype(np.uint32)
+    osc.render(pixels=px)
+    ref = osc.scratch.reshape(-1, 4)[px, :3].astype(np.float64)
+    got = a.reshape(-1, 4)[px, :3].astype(np.float64)
+    assert np.sqrt(np.mean((ref - got) ** 2)) < 1e-4
