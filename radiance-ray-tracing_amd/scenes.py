@@ -274,13 +274,14 @@ class DeviceScene:
 
     def __init__(self, scene, plt=None, shader_text="__kernel void raygen() {}"):
         self.scene = scene
+        self.rtprop = np.array(scene.rtprop).copy()     # device-side RayTraceProperties as last written
         self.plt = plt or rd.Platform.GetPlatform()
         plt = self.plt
         w, h = scene.width, scene.height
         self.width, self.height = w, h
         b = scene.buffers()
         self.rdRTProp = rd.CreateBuffer(plt, rd.RayTraceProperties.itemsize)
-        rd.WriteBuffer(plt, self.rdRTProp, 16, np.array(scene.rtprop))
+        rd.WriteBuffer(plt, self.rdRTProp, 16, self.rtprop)
         self.rdImage = rd.CreateImage(plt, w, h)
         self.rdImageScratch = rd.CreateBuffer(plt, w * h * rd.CHANNEL * 4)
         self.rdCamData = rd.CreateBuffer(plt, rd.PhysicalCamera.itemsize)
@@ -312,11 +313,11 @@ class DeviceScene:
         rd.BindDescriptorSet(self.plt, self.descSet)
 
     def set_rtprop(self, totalSamples=None, batchSize=None, depth=None, debug=None):
-        p = np.array(self.scene.rtprop)
+        p = self.rtprop.copy()
         for k, v in (("totalSamples", totalSamples), ("batchSize", batchSize), ("depth", depth), ("debug", debug)):
             if v is not None:
                 p[k] = v
-        self.scene.rtprop = p
+        self.rtprop = p
         rd.WriteBuffer(self.plt, self.rdRTProp, 16, p)
 
     def render(self):
@@ -328,7 +329,7 @@ class DeviceScene:
         p = p.copy()
         p["totalSamples"] += p["batchSize"]
         rd.WriteBuffer(self.plt, self.rdRTProp, 16, np.array(p))
-        self.scene.rtprop = p
+        self.rtprop = p
         return img
 
     def read_scratch(self):

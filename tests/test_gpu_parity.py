@@ -178,21 +178,25 @@ def test_frame_radiance_rmse(mods, name):
 def test_ray_counts_match_oracle(mods):
     """rays actually traced == the reference algorithm's traceRay count minus the one duplicate
     re-trace the reference issues after each primary miss (shader.cl:243-252 does not break at
-    depth 0, the re-trace misses again and ends the path)"""
+    depth 0, the re-trace misses again and ends the path).  Exact at depth 1 (no transcendental is
+    involved in a primary ray); at depth 3 a handful of bounce rays flip between hit and miss
+    because sin/cos/acos differ by ulps between glibc and OCML -> 1 % tolerance."""
     rd, scenes = mods
-    s = scenes.c0_two_boxes(64, 64, spp=1, depth=3)
-    dev = scenes.DeviceScene(s)
-    dev.render()
-    st = rd.GetTraceStats()
-    osc = ob.OracleScene(s)
-    c = osc.render(counters=True).as_dict()
-    px = np.arange(64 * 64, dtype=np.uint32)
-    o, d = osc.generate_rays(px, np.stack([np.zeros_like(px), np.zeros_like(px), px], 1))
-    primary_misses = int((ob.trace_batch(osc.tlas.tobytes(), o, d)["hit"] == 0).sum())
-    assert st.rays_primary == c["primary"] == 64 * 64
-    assert st.rays_shadow == c["shadow"] == c["rays"][1] == c["hits"] == st.closest_hits
-    assert c["rays"][0] == c["primary"] + c["bounce"]
-    assert st.rays_bounce + primary_misses == c["bounce"]
+    for depth, tol in ((1, 0.0), (3, 0.01)):
+        s = scenes.c0_two_boxes(64, 64, spp=1, depth=depth)
+        osc = ob.OracleScene(s)
+        dev = scenes.DeviceScene(s)
+        dev.render()
+        st = rd.GetTraceStats()
+        c = osc.render(counters=True).as_dict()
+        px = np.arange(64 * 64, dtype=np.uint32)
+        o, d = osc.generate_rays(px, np.stack([np.zeros_like(px), np.zeros_like(px), px], 1))
+        primary_misses = int((ob.trace_batch(osc.tlas.tobytes(), o, d)["hit"] == 0).sum()) if depth > 1 else 0
+        assert st.rays_primary == c["primary"] == 64 * 64
+        assert c["shadow"] == c["rays"][1] == c["hits"] and st.rays_shadow == st.closest_hits
+        assert c["rays"][0] == c["primary"] + c["bounce"]
+        assert abs(int(st.rays_shadow) - c["shadow"]) <= tol * c["shadow"]
+        assert abs(int(st.rays_bounce) + primary_misses - c["bounce"]) <= tol * max(1, c["bounce"])
 
 
 def test_debug_and_degenerate_rtprops(mods):
