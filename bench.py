@@ -46,12 +46,18 @@ def cpu_baseline(scene, budget_s=20.0):
     import oracle_bind as ob
     osc = ob.OracleScene(scene)
     n = scene.width * scene.height
-    cores = os.cpu_count() or 1
-    # calibrate on a small sample, then size the timed sample for ~budget_s
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))           # a 1-GPU box's CPU share is 16 cores
+    # calibrate on a small sample (after a warm-up that starts the thread pool), then size the timed
+    # sample for ~budget_s of CPU work
     rng = np.random.default_rng(0)
-    probe = rng.choice(n, 2048, replace=False).astype(np.uint32)
-    t = time.time(); c = osc.render(nthreads=cores, counters=True, pixels=probe); dt = max(time.time() - t, 1e-3)
-    rate = 2048 / dt
+    probe = rng.choice(n, 4096, replace=False).astype(np.uint32)
+    osc.render(nthreads=cores, pixels=probe[:256])
+    t = time.time(); osc.render(nthreads=cores, pixels=probe); dt = max(time.time() - t, 1e-3)
+    rate = 4096 / dt
     m = int(min(n, max(4096, rate * budget_s)))
     px = rng.choice(n, m, replace=False).astype(np.uint32)
     osc.scratch[:] = 0

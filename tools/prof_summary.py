@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""prof_summary.py -- condenses rocprofv3 output (gpurun_out/prof/{stats,fetch,write}) into the small
+files committed under profiles/: the --stats kernel table as-is, and a per-kernel PMC summary with
+the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are in KiB; FETCH_SIZE reads exactly 1/2 of a wide coalesced stream on gfx950, so the
+read side is reported both raw and doubled.
+
+usage: tools/prof_summary.py <prof_dir> <profiles_dir> <tag>
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    if not os.path.exists(path):
+        return {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    return {k: {"launches": v[0], "avg_KiB_per_launch": v[1] / v[0]} for k, v in agg.items()}
+
+
+def main():
+    prof, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(out, exist_ok=True)
+    st = os.path.join(prof, "stats", "r1_kernel_stats.csv")
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(out, "%s_kernel_stats.csv" % tag))
+    fetch = per_kernel(os.path.join(prof, "fetch", "r1_counter_collection.csv"), "FETCH_SIZE")
+    write = per_kernel(os.path.join(prof, "write", "r1_counter_collection.csv"), "WRITE_SIZE")
+    summ = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("rdx::"):
+            continue
+        f = fetch.get(k, {}).get("avg_KiB_per_launch", 0.0)
+        w = write.get(k, {}).get("avg_KiB_per_launch", 0.0)
+        summ[k] = {
+            "launches_fetch_pass": fetch.get(k, {}).get("launches", 0),
+            "launches_write_pass": write.get(k, {}).get("launches", 0),
+            "FETCH_SIZE_KiB_per_launch_raw": round(f, 1),
+            "WRITE_SIZE_KiB_per_launch": round(w, 1),
+            "hbm_read_bytes_per_launch_corrected_x2": int(f * 1024 * 2),
+            "hbm_write_bytes_per_launch": int(w * 1024),
+            "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024),
+        }
+    with open(os.path.join(out, "%s_pmc_hbm.json" % tag), "w") as fjs:
+        json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled "
+                           "per the gfx950 calibration for wide coalesced reads (uncalibrated for other widths)",
+                   "kernels": summ}, fjs, indent=1)
+    print(json.dumps(summ, indent=1))
+
+
+if __name__ == "__main__":
+    main()
