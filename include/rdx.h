@@ -118,7 +118,9 @@ int         rdx_get_trace_stats(rdx_trace_stats* out);
 /* 0 = per-stage HIP events off (default), 1 = on (adds launch gaps; for profiling only) */
 int         rdx_set_profiling(int on);
 /* knobs: "chunk_paths" (paths in flight per chunk), "count_visits" (0/1: also count node /
- * triangle visits; slower, for the roofline byte model) */
+ * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 2 = wave-
+ * cooperative (default), 1 = per-lane wide nodes, 0 = reference order; all three give identical
+ * results, the option exists for A/B measurements and cross-checks) */
 int         rdx_set_option(const char* name, int64_t value);
 
 /* Test seams: run single stages on caller-supplied batches (device or host pointers are NOT
@@ -131,9 +133,13 @@ typedef struct rdx_hit {
     uint32_t hit;
     float    transform[16];
 } rdx_hit;      /* mirrors struct HitData, radiance/shader/radiance.cl:8-18 (+ the hit flag) */
-/* visit8 (optional): {top_nodes, instances, bot_nodes, triangles} visit counts summed over the batch */
+/* mode 0: production kernel (wide nodes, fast slab test; for sbtRecordOffset 2 only `hit` is
+ *         meaningful -- any accepted candidate ends a shadow ray);
+ * mode 1: reference-order kernel (the reference's own DFS order: full HitData also for shadow rays).
+ * visit4 (optional, implies mode 1): {top_nodes, instances, bot_nodes, triangles} visit counts of
+ * the reference algorithm summed over the batch. */
 int         rdx_trace_batch(rdx_buffer tlas, const float* origins_xyz, const float* dirs_xyz, uint32_t n,
-                            float tmin, float tmax, int sbtRecordOffset, rdx_hit* out, uint64_t* visit4);
+                            float tmin, float tmax, int sbtRecordOffset, int mode, rdx_hit* out, uint64_t* visit4);
 typedef struct rdx_payload {
     float color[3]; uint32_t hit; float nextFactor[3]; float nextRayOrigin[3]; float nextRayDirection[3];
 } rdx_payload;  /* mirrors struct Payload, samples/shader.cl:4-13 */

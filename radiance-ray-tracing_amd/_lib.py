@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librdx.so")
+LIB_PATH = os.environ.get("RDX_LIB") or os.path.join(HERE, "librdx.so")     # RDX_LIB: experiment builds only
 
 
 class rdx_instance(C.Structure):
@@ -68,7 +68,7 @@ SIGNATURES = {
     "rdx_get_trace_stats": (C.c_int, [C.POINTER(rdx_trace_stats)]),
     "rdx_set_profiling": (C.c_int, [C.c_int]),
     "rdx_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
-    "rdx_trace_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int,
+    "rdx_trace_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p]),
     "rdx_material_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rdx_generate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),

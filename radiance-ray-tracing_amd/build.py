@@ -11,6 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdx.so")
+# experiment builds: RDX_DEFINES="-DFOO -DBAR" RDX_LIB_NAME=librdx_foo.so python build.py --force
+EXTRA = os.environ.get("RDX_DEFINES", "").split()
+if os.environ.get("RDX_LIB_NAME"):
+    LIB = os.path.join(HERE, os.environ["RDX_LIB_NAME"])
 SOURCES = ["kernels.hip", "rdx_runtime.cpp", "bvh_build.cpp"]
 HEADERS = ["kernels.h", "stages.h", "device_math.h", "rdx_types.h", "bvh_build.h", "sbt_generated.h",
            os.path.join("..", "..", "include", "rdx.h")]
@@ -33,7 +37,7 @@ def build(force=False, verbose=True):
     # regenerate the SBT tables from samples/sbt.json
     gen = os.path.join(HERE, "..", "tools", "genSBT.py")
     subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [HIPCC] + FLAGS + EXTRA + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

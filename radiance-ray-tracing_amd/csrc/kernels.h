@@ -14,7 +14,9 @@ struct AccelView {                 // derived traversal layout (see rdx_types.h)
     const DInst* insts;
     const DNode* bnodes;
     const DTri*  tris;
+    const DWide* wide;             // wide BLAS nodes (production kernels)
     uint32_t stackNeed;            // worst-case stack entries of an exhaustive DFS
+    uint32_t kernel;               // 2 = wave-cooperative (default), 1 = per-lane wide, 0 = reference order
 };
 
 struct SceneArgs {                 // descriptor slots 4-10 (samples/shader.cl:175-190)
@@ -70,7 +72,7 @@ void launch_pack_tiles(hipStream_t st, const uint8_t* image, uint8_t* packed, ui
 
 // test seams
 void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, const float* d, uint32_t n, float tmin,
-                        float tmax, int rec, rdx_hit* out, unsigned long long* visit);
+                        float tmax, int rec, rdx_hit* out, unsigned long long* visit, int mode);
 void launch_material_batch(hipStream_t st, const SceneArgs& sc, const rdx_hit* hits, const float* dirs,
                            const uint32_t* pixels, const uint32_t* frames, const int32_t* depths, uint32_t n,
                            rdx_payload* out);

@@ -136,6 +136,189 @@ __device__ __forceinline__ void traverse(const AccelView& A, f3 o, f3 d, float t
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// production traversal ("wide" layout)
+// ---------------------------------------------------------------------------------------------
+// Same visit set and same arithmetic per test as the reference-order walk above, reorganised for the
+// machine:
+//   * DWide nodes: one 64-byte fetch carries both children's boxes; leaf children are embedded in
+//     the parent, so a leaf costs no node fetch and the dependent-load chain per ray halves.
+//   * slab test: (b - o) * (1/d) with a conservative error band; only a test that lands inside the
+//     band (|tFar - max(tNear,0)| within 8 ulp-ish) is redone with the reference's IEEE divisions, so
+//     the DECISION is always the reference's (see DESIGN.md "fast slab test" for the bound).
+//   * visiting order inside a BLAS is free: a closest-hit candidate wins on (t, triangle slot), which
+//     is exactly "first strictly-smaller t in DFS order" because triangle slots are numbered in DFS
+//     leaf order (bvh.cpp:487-497); any-hit rays only report whether a candidate exists.
+struct RayInst {      // per ray, per entered instance
+    f3 o, d, rcp;
+    bool exactOnly;   // a direction component is (nearly) zero: keep to the division form
+};
+
+__device__ __forceinline__ bool slab_fast(const RayInst& R, f3 bmin, f3 bmax)
+{
+#ifdef RDX_V_EXACTSLAB
+    { float4 a = make_float4(bmin.x, bmin.y, bmin.z, 0.f), b = make_float4(bmax.x, bmax.y, bmax.z, 0.f); return slab_hit(R.o, R.d, a, b); }
+#endif
+#ifdef RDX_V_NOBAND
+    { const f3 tA = (bmin - R.o) * R.rcp, tB = (bmax - R.o) * R.rcp;
+      const float tn = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
+      const float tf = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
+      return tf > fmaxf(tn, 0.0f); }
+#endif
+    if (R.exactOnly) {
+        float4 a = make_float4(bmin.x, bmin.y, bmin.z, 0.f), b = make_float4(bmax.x, bmax.y, bmax.z, 0.f);
+        return slab_hit(R.o, R.d, a, b);
+    }
+    const f3 tA = (bmin - R.o) * R.rcp, tB = (bmax - R.o) * R.rcp;
+    const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
+    const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
+    const float n0 = fmaxf(tNear, 0.0f);
+    const float band = 4.8e-7f * (fabsf(tFar) + n0) + 1e-30f;
+    const float diff = tFar - n0;
+    if (diff > band) return true;
+    if (diff < -band) return false;
+    float4 a = make_float4(bmin.x, bmin.y, bmin.z, 0.f), b = make_float4(bmax.x, bmax.y, bmax.z, 0.f);
+    return slab_hit(R.o, R.d, a, b);        // inside the band (or non-finite): the reference's own form decides
+}
+
+struct Best {
+    float t, b1, b2;
+    uint32_t slot, inst;
+    bool hit;
+};
+
+// Möller–Trumbore on triangle slots [start, start+count); returns true if the walk must stop (any-hit)
+template <int REC>
+__device__ __forceinline__ bool leaf_tris(const AccelView& A, const RayInst& R, uint32_t start, uint32_t count,
+                                          uint32_t curInst, float tmin, float tmax, Best& B)
+{
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t slot = start + i;
+        const float4* tp = reinterpret_cast<const float4*>(A.tris + slot);
+        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+        const f3 e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
+        const f3 rce2 = cross3(R.d, e2);
+        const float det = dot3(e1, rce2);
+        if (det == 0) continue;
+        const float inv_det = 1.0f / det;
+        const f3 s = R.o - mk3(q0.x, q0.y, q0.z);
+        const float b1 = inv_det * dot3(s, rce2);
+        const f3 sce1 = cross3(s, e1);
+        const float b2 = inv_det * dot3(R.d, sce1);
+        const float t = inv_det * dot3(e2, sce1);
+        if (b1 < 0 || b1 > 1) continue;
+        if (b2 < 0 || b1 + b2 > 1) continue;
+        if (!(t > 0)) continue;
+        if (!(t > tmin && t < tmax)) continue;
+        // reference: accept iff t < best in DFS order  <=>  (t, slot) lexicographically smaller
+        const bool better = (t < B.t) || (t == B.t && B.inst == curInst && slot < B.slot);
+        if (better) {
+            B.t = t; B.b1 = b1; B.b2 = b2; B.slot = slot; B.inst = curInst; B.hit = true;
+            bool cont = true;
+            callAnyHit(cont, (int)A.insts[curInst].SBTOffset + REC);
+            if (!cont) return true;
+        }
+    }
+    return false;
+}
+
+// stack / work-item encoding of a run of triangle slots (a leaf, or an 8-triangle piece of a big one)
+__device__ __forceinline__ uint32_t leaf_item(uint32_t start, uint32_t count) { return TAG_LEAF | ((count - 1u) << LEAF_START_BITS) | start; }
+
+template <int REC>
+__device__ __forceinline__ void traverse_wide(const AccelView& A, f3 o, f3 d, float tmin, float tmax,
+                                              uint32_t* __restrict__ stack, uint32_t stride, Best& B)
+{
+    B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
+    uint32_t sp = 0;
+    uint32_t cur = TAG_TLAS | 0u;            // work item: TLAS node, instance entry, wide BLAS node or triangle run
+    RayInst R;                               // object-space ray of the instance being walked
+    R.o = o; R.d = d; R.rcp = mk3(0.f, 0.f, 0.f); R.exactOnly = true;
+    uint32_t curInst = 0;
+    // One flat loop, one homogeneous work item per lane per iteration (a node: two box tests; a
+    // triangle run: up to 8 Möller–Trumbore tests), so lanes of a wave stay in the same code.
+    for (;;) {
+        const uint32_t tag = cur & TAG_MASK;
+        if (tag == TAG_LEAF) {
+            const uint32_t start = cur & LEAF_START_MASK, count = ((cur >> LEAF_START_BITS) & 7u) + 1u;
+            if (leaf_tris<REC>(A, R, start, count, curInst, tmin, tmax, B)) return;
+        } else if (tag == TAG_BLAS) {
+            const float4* wp = reinterpret_cast<const float4*>(A.wide + (cur & IDX_MASK));
+            const float4 l0 = wp[0], l1 = wp[1], r0 = wp[2], r1 = wp[3];
+            uint32_t item0 = RDX_MISS, item1 = RDX_MISS;        // RDX_MISS = 0xffffffff is never a valid item
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float4 bmin = c ? r0 : l0, bmax = c ? r1 : l1;
+                const uint32_t d0 = f2u(bmin.w), d1 = f2u(bmax.w);
+                uint32_t item = RDX_MISS;
+                if (d1 & WIDE_LEAF) {
+                    uint32_t cnt = d1 & 0x7fffffffu, st = d0;
+                    while (cnt > 8u) { stack[sp * stride] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }   // rare: oversized leaf
+                    if (cnt) item = leaf_item(st, cnt);
+                } else if (slab_fast(R, mk3(bmin.x, bmin.y, bmin.z), mk3(bmax.x, bmax.y, bmax.z))) {
+                    item = d0;
+                }
+                if (c == 0) item0 = item; else item1 = item;
+            }
+            if (item0 != RDX_MISS) {
+                if (item1 != RDX_MISS) { stack[sp * stride] = item1; ++sp; }
+                cur = item0;
+                continue;
+            }
+            if (item1 != RDX_MISS) { cur = item1; continue; }
+        } else if (tag == TAG_TLAS) {
+            const float4* np = reinterpret_cast<const float4*>(A.tnodes + (cur & IDX_MASK));
+            const float4 bmin = np[0], bmax = np[1];
+            const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
+            if (!(w.x & LEAF_BIT)) {
+                if (slab_hit(o, d, bmin, bmax)) {
+                    stack[sp * stride] = TAG_TLAS | w.y; ++sp;
+                    cur = TAG_TLAS | w.x;
+                    continue;
+                }
+            } else {
+                const uint32_t count = w.x & 0x7fffffffu;
+                if (w.z == TYPE_INST && count > 0) {
+                    for (uint32_t i = count - 1; i >= 1; --i) { stack[sp * stride] = TAG_INST | (w.y + i); ++sp; }
+                    cur = TAG_INST | w.y;
+                    continue;
+                }
+            }
+        } else {   // TAG_INST: enter the instance (radiance.cl:161-169)
+            curInst = cur & IDX_MASK;
+            const float4* ip = reinterpret_cast<const float4*>(A.insts + curInst);
+            float m[16];
+            *reinterpret_cast<float4*>(m + 0) = ip[0];
+            *reinterpret_cast<float4*>(m + 4) = ip[1];
+            *reinterpret_cast<float4*>(m + 8) = ip[2];
+            *reinterpret_cast<float4*>(m + 12) = ip[3];
+            R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
+            R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
+            R.rcp = mk3(1.0f / R.d.x, 1.0f / R.d.y, 1.0f / R.d.z);
+            const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
+            const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
+            R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
+            const uint4 rd = *reinterpret_cast<const uint4*>(ip + 9);
+            if (rd.y & WIDE_LEAF) {
+                uint32_t cnt = rd.y & 0x7fffffffu, st = rd.x;
+                while (cnt > 8u) { stack[sp * stride] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }
+                if (cnt) { cur = leaf_item(st, cnt); continue; }
+            } else {
+                const float4 rmin = ip[10], rmax = ip[11];
+                if (slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z))) { cur = rd.x; continue; }
+            }
+        }
+        if (sp == 0) return;
+        --sp;
+        cur = stack[sp * stride];
+    }
+}
+
+} // namespace rdx
+#include "traverse_coop.h"
+namespace rdx {
+
 extern __shared__ uint32_t s_stack[];
 
 // COUNT builds: add this lane's visit counts to visit[cls*4 + {top, inst, bot, tri}]
@@ -217,11 +400,18 @@ k_extend(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, float t
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *nPtr) return;
     const float4 ro = ps.rayO[i], rd = ps.rayD[i];
-    TraceResult r;
-    traverse<1, COUNT>(A, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
-    ps.hitA[i] = make_float4(r.t, r.b1, r.b2, u2f(r.prim));
-    ps.hitInst[i] = r.hit ? r.inst : RDX_MISS;
-    if (COUNT) flush_visits(visit, 0, r);
+    if (COUNT) {       // reference-order walk: visit counters of the reference algorithm
+        TraceResult r;
+        traverse<1, true>(A, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
+        ps.hitA[i] = make_float4(r.t, r.b1, r.b2, u2f(r.prim));
+        ps.hitInst[i] = r.hit ? r.inst : RDX_MISS;
+        flush_visits(visit, 0, r);
+    } else {
+        Best b;
+        traverse_wide<1>(A, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax, s_stack + threadIdx.x, blockDim.x, b);
+        ps.hitA[i] = make_float4(b.t, b.b1, b.b2, b.hit ? u2f(A.tris[b.slot].primID) : 0.0f);
+        ps.hitInst[i] = b.hit ? b.inst : RDX_MISS;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,12 +511,20 @@ k_shadow(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__
     if (tn.w != 0.0f) {
         const float* ld = sc.scene->lights[0].direction;
         const f3 L = normalize3(mk3(-ld[0], -ld[1], -ld[2]));     // shader.cl:471-476
-        TraceResult r;
-        traverse<2, COUNT>(A, mk3(so.x, so.y, so.z), L, tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
-        if (COUNT) flush_visits(visit, 1, r);
+        bool anyHit; uint32_t hitInst;
+        if (COUNT) {
+            TraceResult r;
+            traverse<2, true>(A, mk3(so.x, so.y, so.z), L, tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
+            flush_visits(visit, 1, r);
+            anyHit = r.hit; hitInst = r.inst;
+        } else {
+            Best b;
+            traverse_wide<2>(A, mk3(so.x, so.y, so.z), L, tmin, tmax, s_stack + threadIdx.x, blockDim.x, b);
+            anyHit = b.hit; hitInst = b.inst;
+        }
         // hit -> closest-hit row 2 `shadow` sets payload.hit; miss -> row 4 `shadowMiss` clears it
         Payload sp; sp.hit = false;
-        if (r.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[r.inst].SBTOffset + 2, sp, hh, sv, L, 0, 0, 0, false); }
+        if (anyHit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[hitInst].SBTOffset + 2, sp, hh, sv, L, 0, 0, 0, false); }
         else callMiss(4, sp);
         occluded = sp.hit;
     }
@@ -425,20 +623,8 @@ k_pack_tiles(const uint8_t* __restrict__ image, uint8_t* __restrict__ packed, ui
     else pk[g] = img[ii];
 }
 
-// ---------------------------------------------------------------------------------------------
-// test seams
-// ---------------------------------------------------------------------------------------------
-template <int REC, bool COUNT>
-__global__ void __launch_bounds__(RDX_BLOCK)
-k_trace_batch(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, float tmin, float tmax,
-              rdx_hit* __restrict__ out, unsigned long long* __restrict__ visit)
+__device__ __forceinline__ void write_hit_record(const AccelView& A, const TraceResult& r, f3 ro, f3 rd, rdx_hit& dst)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    TraceResult r;
-    traverse<REC, COUNT>(A, ro, rd, tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
-    if (COUNT) flush_visits(visit, REC - 1, r);
     rdx_hit h;
     h.hit = r.hit ? 1u : 0u;
     h.distance = r.t;
@@ -457,7 +643,103 @@ k_trace_batch(AccelView A, const float* __restrict__ o, const float* __restrict_
         h.barycentric[0] = h.barycentric[1] = h.barycentric[2] = 0.f;
         for (int k = 0; k < 16; ++k) h.transform[k] = 0.f;
     }
-    out[i] = h;
+    dst = h;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// wave-cooperative extend / shadow (production): see traverse_coop.h
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_extend_coop(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, float tmin, float tmax)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *nPtr;
+    if (blockIdx.x * blockDim.x >= n) return;                  // whole block idle (block-uniform)
+    const bool active = i < n;
+    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (active) { ro = ps.rayO[i]; rd = ps.rayD[i]; }
+    Best b;
+    traverse_coop<1>(A, active, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax,
+                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed, b);
+    if (!active) return;
+    ps.hitA[i] = make_float4(b.t, b.b1, b.b2, b.hit ? u2f(A.tris[b.slot].primID) : 0.0f);
+    ps.hitInst[i] = b.hit ? b.inst : RDX_MISS;
+}
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_shadow_coop(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t lastBounce,
+              uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *nPtr;
+    if (blockIdx.x * blockDim.x >= n) return;
+    bool active = i < n;
+    float4 so = make_float4(0.f, 0.f, 0.f, 0.f), tn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) { so = ps.shO[i]; tn = ps.thrN[i]; }
+    const bool wants = active && tn.w != 0.0f;
+    const float* ld = sc.scene->lights[0].direction;
+    const f3 Ldir = normalize3(mk3(-ld[0], -ld[1], -ld[2]));     // shader.cl:471-476
+    Best b;
+    traverse_coop<2>(A, wants, mk3(so.x, so.y, so.z), Ldir, tmin, tmax,
+                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed, b);
+    if (!active) return;
+    bool occluded = false;
+    if (wants) {
+        Payload sp; sp.hit = false;
+        if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[b.inst].SBTOffset + 2, sp, hh, sv, Ldir, 0, 0, 0, false); }
+        else callMiss(4, sp);
+        occluded = sp.hit;
+    }
+    const float4 c = occluded ? ps.colSh[i] : ps.colLit[i];
+    const float4 no = ps.nextO[i], nd = ps.nextD[i];
+    if (lastBounce) { store_sample(ps, nPixels, sampleBase, f2u(no.w), f2u(nd.w), mk3(c.x, c.y, c.z)); return; }
+    ps.rayO[i] = make_float4(no.x, no.y, no.z, so.w);
+    ps.rayD[i] = make_float4(nd.x, nd.y, nd.z, no.w);
+    ps.thr[i] = make_float4(tn.x, tn.y, tn.z, nd.w);
+    ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
+}
+
+template <int REC>
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, float tmin, float tmax,
+                   rdx_hit* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;
+    f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(0.f, 0.f, 1.f);
+    if (active) { ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]); }
+    Best b;
+    traverse_coop<REC>(A, active, ro, rd, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed, b);
+    if (!active) return;
+    TraceResult r;
+    r.t = b.t; r.b1 = b.b1; r.b2 = b.b2; r.inst = b.inst; r.hit = b.hit;
+    r.prim = b.hit ? A.tris[b.slot].primID : 0;
+    write_hit_record(A, r, ro, rd, out[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// test seams
+// ---------------------------------------------------------------------------------------------
+template <int REC, bool COUNT, bool WIDE>
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_trace_batch(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, float tmin, float tmax,
+              rdx_hit* __restrict__ out, unsigned long long* __restrict__ visit)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    TraceResult r;
+    if (WIDE) {
+        Best b;
+        traverse_wide<REC>(A, ro, rd, tmin, tmax, s_stack + threadIdx.x, blockDim.x, b);
+        r.t = b.t; r.b1 = b.b1; r.b2 = b.b2; r.inst = b.inst; r.hit = b.hit;
+        r.prim = b.hit ? A.tris[b.slot].primID : 0;
+    } else {
+        traverse<REC, COUNT>(A, ro, rd, tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
+        if (COUNT) flush_visits(visit, REC - 1, r);
+    }
+    write_hit_record(A, r, ro, rd, out[i]);
 }
 
 __global__ void __launch_bounds__(RDX_BLOCK)
@@ -533,12 +815,27 @@ void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& p
                        sampleBegin, sampleCount, totalSamples);
 }
 
+// threads per block for the cooperative kernels: per-wave LDS = stack + queue + ray table
+static inline uint32_t coop_threads(uint32_t need, size_t& ldsBytes)
+{
+    const size_t perWave = (size_t)coop_words_per_wave(need) * 4;
+    uint32_t threads = RDX_BLOCK;
+    while (threads > 64 && perWave * (threads / 64) > 52 * 1024) threads >>= 1;
+    ldsBytes = perWave * (threads / 64);
+    return threads;
+}
+
 void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,
                    float tmin, float tmax, unsigned long long* visit)
 {
     if (!nMax) return;
+    if (!visit && av.kernel == 2) {
+        size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
+        hipLaunchKernelGGL(k_extend_coop, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, ps, nPtr, tmin, tmax);
+        return;
+    }
     size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);
-    if (visit)
+    if (visit || av.kernel == 0)
         hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, ps, nPtr, tmin, tmax, visit);
     else
         hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, ps, nPtr, tmin, tmax, visit);
@@ -557,8 +854,14 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
                    unsigned long long* visit)
 {
     if (!nMax) return;
+    if (!visit && av.kernel == 2) {
+        size_t ldsc; const uint32_t thc = coop_threads(av.stackNeed, ldsc);
+        hipLaunchKernelGGL(k_shadow_coop, dim3(blocks_for(nMax, thc)), dim3(thc), ldsc, st, av, sc, ps, nPtr,
+                           lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
+        return;
+    }
     size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);
-    if (visit)
+    if (visit || av.kernel == 0)
         hipLaunchKernelGGL(k_shadow<true>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, sc, ps, nPtr,
                            lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax, visit);
     else
@@ -593,18 +896,22 @@ void launch_pack_tiles(hipStream_t st, const uint8_t* image, uint8_t* packed, ui
 }
 
 void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, const float* d, uint32_t n, float tmin,
-                        float tmax, int rec, rdx_hit* out, unsigned long long* visit)
+                        float tmax, int rec, rdx_hit* out, unsigned long long* visit, int mode)
 {
     if (!n) return;
+    if (!visit && mode == 0 && av.kernel == 2) {
+        size_t ldsc; const uint32_t thc = coop_threads(av.stackNeed, ldsc);
+        if (rec == 2) hipLaunchKernelGGL(k_trace_batch_coop<2>, dim3(blocks_for(n, thc)), dim3(thc), ldsc, st, av, o, d, n, tmin, tmax, out);
+        else hipLaunchKernelGGL(k_trace_batch_coop<1>, dim3(blocks_for(n, thc)), dim3(thc), ldsc, st, av, o, d, n, tmin, tmax, out);
+        return;
+    }
     size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);
     const dim3 g(blocks_for(n, th)), b(th);
-    if (rec == 2) {
-        if (visit) hipLaunchKernelGGL((k_trace_batch<2, true>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
-        else hipLaunchKernelGGL((k_trace_batch<2, false>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
-    } else {
-        if (visit) hipLaunchKernelGGL((k_trace_batch<1, true>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
-        else hipLaunchKernelGGL((k_trace_batch<1, false>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit);
-    }
+#define RDX_TB(REC, COUNT, WIDE) hipLaunchKernelGGL((k_trace_batch<REC, COUNT, WIDE>), g, b, lds, st, av, o, d, n, tmin, tmax, out, visit)
+    if (visit) { if (rec == 2) RDX_TB(2, true, false); else RDX_TB(1, true, false); }
+    else if (mode == 1 || av.kernel == 0) { if (rec == 2) RDX_TB(2, false, false); else RDX_TB(1, false, false); }
+    else { if (rec == 2) RDX_TB(2, false, true); else RDX_TB(1, false, true); }
+#undef RDX_TB
 }
 
 void launch_material_batch(hipStream_t st, const SceneArgs& sc, const rdx_hit* hits, const float* dirs,

@@ -31,14 +31,17 @@ using namespace rdx;
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
     DNode* tnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
+    DWide* wide = nullptr;
     uint32_t stackNeed = 1;
+    bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
     void release()
     {
         if (tnodes) HIP_IGN(hipFree(tnodes));
         if (insts) HIP_IGN(hipFree(insts));
         if (bnodes) HIP_IGN(hipFree(bnodes));
         if (tris) HIP_IGN(hipFree(tris));
-        tnodes = nullptr; insts = nullptr; bnodes = nullptr; tris = nullptr;
+        if (wide) HIP_IGN(hipFree(wide));
+        tnodes = nullptr; insts = nullptr; bnodes = nullptr; tris = nullptr; wide = nullptr;
     }
 };
 
@@ -82,6 +85,7 @@ struct Context {
     // options
     int64_t chunkPaths = 16ll << 20;
     bool countVisits = false, profiling = false;
+    int kernel = 2;                         // traversal kernel: 2 cooperative, 1 per-lane wide, 0 reference order
     rdx_trace_stats stats{};
 };
 Context g;
@@ -154,8 +158,11 @@ int derive_accel(rdx_buffer_s* tb)
     }
     std::vector<DNode> dB;
     std::vector<DTri> dTri;
+    std::vector<DWide> dW;
     std::vector<DInst> dI(nInst);
-    struct BlasInfo { uint32_t nodeBase; uint32_t need; };
+    struct BlasInfo { uint32_t nodeBase; uint32_t need; uint32_t triBase; uint32_t rootDesc0, rootDesc1; float rootMin[3], rootMax[3]; };
+    bool coopOK = nInst <= 1024;
+    uint32_t maxLeafChunks = 0;             // extra stack entries an oversized (> 8 triangle) leaf can push
     std::map<uint32_t, BlasInfo> blasAt;    // byte offset -> merged-array base
     for (uint32_t k = 0; k < nInst; ++k) {
         const BlobInst& bi = binst[k];
@@ -183,12 +190,14 @@ int derive_accel(rdx_buffer_s* tb)
                 std::memcpy(&d, &bn[i], sizeof(BlobNode));
                 if (bn[i].w0 & LEAF_BIT) {
                     if ((uint64_t)bn[i].w1 + (bn[i].w0 & 0x7fffffffu) > nTris) return fail("BLAS blob: leaf range out of bounds");
+                    maxLeafChunks = std::max(maxLeafChunks, 2u * (((bn[i].w0 & 0x7fffffffu) + 7u) / 8u));
                     d.w1 = bn[i].w1 + triBase;
                 } else {
                     if (bn[i].w0 >= nNodes || bn[i].w1 >= nNodes) return fail("BLAS blob: child index out of range");
                     d.w0 = bn[i].w0 + nodeBase; d.w1 = bn[i].w1 + nodeBase;
                 }
             }
+            if ((uint64_t)triBase + nTris > LEAF_START_MASK) return fail("too many triangles for 27-bit triangle-run references");
             dTri.resize(triBase + nTris);
             for (uint32_t i = 0; i < nTris; ++i) {
                 const BlobTri& t = bt[i];
@@ -200,7 +209,30 @@ int derive_accel(rdx_buffer_s* tb)
                 d.e1[0] = v1[0] - v0[0]; d.e1[1] = v1[1] - v0[1]; d.e1[2] = v1[2] - v0[2]; d._p0 = 0;   // radiance.cl:215
                 d.e2[0] = v2[0] - v0[0]; d.e2[1] = v2[1] - v0[1]; d.e2[2] = v2[2] - v0[2]; d._p1 = 0;   // radiance.cl:216
             }
-            BlasInfo info{nodeBase, blas_need(bn, 0)};
+            // wide layout: one record per inner node, numbered in the same DFS pre-order
+            const uint32_t wideBase = (uint32_t)dW.size();
+            std::vector<uint32_t> wideIdx(nNodes, 0);
+            uint32_t nInner = 0;
+            for (uint32_t i = 0; i < nNodes; ++i) if (!(bn[i].w0 & LEAF_BIT)) wideIdx[i] = nInner++;
+            if ((uint64_t)wideBase + nInner >= (1u << 30)) return fail("too many BVH nodes for 30-bit references");
+            auto desc = [&](uint32_t c, uint32_t& d0, uint32_t& d1) {
+                if (bn[c].w0 & LEAF_BIT) { d0 = bn[c].w1 + triBase; d1 = WIDE_LEAF | (bn[c].w2 == TYPE_TRIG ? (bn[c].w0 & 0x7fffffffu) : 0u); }
+                else { d0 = wideBase + wideIdx[c]; d1 = 0; }
+            };
+            dW.resize(wideBase + nInner);
+            for (uint32_t i = 0; i < nNodes; ++i) {
+                if (bn[i].w0 & LEAF_BIT) continue;
+                DWide& w = dW[wideBase + wideIdx[i]];
+                const BlobNode& L = bn[bn[i].w0]; const BlobNode& Rn = bn[bn[i].w1];
+                for (int k = 0; k < 3; ++k) { w.lmin[k] = L.bottom[k]; w.lmax[k] = L.top[k]; w.rmin[k] = Rn.bottom[k]; w.rmax[k] = Rn.top[k]; }
+                desc(bn[i].w0, w.ld0, w.ld1);
+                desc(bn[i].w1, w.rd0, w.rd1);
+            }
+            BlasInfo info{};
+            info.nodeBase = nodeBase; info.need = blas_need(bn, 0); info.triBase = triBase;
+            if (nTris > (1u << 22)) coopOK = false;
+            desc(0, info.rootDesc0, info.rootDesc1);
+            for (int k = 0; k < 3; ++k) { info.rootMin[k] = bn[0].bottom[k]; info.rootMax[k] = bn[0].top[k]; }
             it = blasAt.emplace(bi.instanceOffset, info).first;
         }
         DInst& d = dI[k];
@@ -209,6 +241,8 @@ int derive_accel(rdx_buffer_s* tb)
         inverse_mat4(bi.m, d.inv);          // zeros stay if singular (oracle convention; reference: uninitialised)
         d.SBTOffset = bi.SBTOffset; d.instanceID = bi.instanceID; d.customInstanceID = bi.customInstanceID;
         d.blasRoot = it->second.nodeBase;
+        d.rootDesc0 = it->second.rootDesc0; d.rootDesc1 = it->second.rootDesc1; d._p0 = it->second.triBase;
+        for (int k = 0; k < 3; ++k) { d.rootMin[k] = it->second.rootMin[k]; d.rootMax[k] = it->second.rootMax[k]; }
     }
     // stack need: TLAS part
     std::vector<uint32_t> needT(nTop, 0);
@@ -224,7 +258,7 @@ int derive_accel(rdx_buffer_s* tb)
         }
     }
     auto ac = std::make_unique<AccelCache>();
-    ac->stackNeed = std::max(1u, needT[0]);
+    ac->stackNeed = std::max(1u, needT[0]) + 1u + maxLeafChunks;
     if (ac->stackNeed > 2560) return fail("BVH too deep for the LDS traversal stack (%u entries)", ac->stackNeed);
     auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
@@ -237,6 +271,8 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->insts, dI));
     HIP_OK(up(ac->bnodes, dB));
     HIP_OK(up(ac->tris, dTri));
+    HIP_OK(up(ac->wide, dW));
+    ac->coopOK = coopOK && dTri.size() < (1u << 26);
     ac->version = tb->version;
     if (tb->accel) tb->accel->release();
     tb->accel = std::move(ac);
@@ -247,6 +283,8 @@ AccelView view_of(const rdx_buffer_s* tb)
 {
     AccelView v{};
     v.tnodes = tb->accel->tnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
+    v.wide = tb->accel->wide;
+    v.kernel = (g.kernel == 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
     v.stackNeed = tb->accel->stackNeed;
     return v;
 }
@@ -657,6 +695,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!name) return fail("rdx_set_option: null name");
     if (!strcmp(name, "chunk_paths")) { if (value < 1) return fail("chunk_paths must be >= 1"); g.chunkPaths = value; return 0; }
     if (!strcmp(name, "count_visits")) { g.countVisits = value != 0; return 0; }
+    if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail("kernel must be 0, 1 or 2"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
 }
 extern "C" int rdx_get_trace_stats(rdx_trace_stats* out) { if (!out) return fail("null"); *out = g.stats; return 0; }
@@ -785,8 +824,9 @@ template <class T> struct DevArray {
 }
 
 extern "C" int rdx_trace_batch(rdx_buffer tlas, const float* o, const float* d, uint32_t n, float tmin, float tmax,
-                               int rec, rdx_hit* out, uint64_t* visit4)
+                               int rec, int mode, rdx_hit* out, uint64_t* visit4)
 {
+    if (mode != 0 && mode != 1) return fail("rdx_trace_batch: mode must be 0 (production) or 1 (reference order)");
     if (!g.initialized) return fail("rdx_init has not been called");
     if (!tlas || !known_buffer(tlas)) return fail("rdx_trace_batch: invalid TLAS handle");
     if (rec != 1 && rec != 2) return fail("rdx_trace_batch: sbtRecordOffset must be 1 or 2");
@@ -794,9 +834,13 @@ extern "C" int rdx_trace_batch(rdx_buffer tlas, const float* o, const float* d, 
     DevArray<float> dO, dD; DevArray<rdx_hit> dH;
     HIP_OK(dO.upload(o, 3 * (size_t)n)); HIP_OK(dD.upload(d, 3 * (size_t)n)); HIP_OK(dH.alloc(n));
     if (visit4) HIP_OK(hipMemsetAsync(g.dVisit, 0, 8 * sizeof(unsigned long long), g.stream));
-    launch_trace_batch(g.stream, view_of(tlas), dO.p, dD.p, n, tmin, tmax, rec, dH.p, visit4 ? g.dVisit : nullptr);
+    HIP_OK(hipEventRecord(g.evA, g.stream));
+    launch_trace_batch(g.stream, view_of(tlas), dO.p, dD.p, n, tmin, tmax, rec, dH.p, visit4 ? g.dVisit : nullptr, mode);
+    HIP_OK(hipEventRecord(g.evB, g.stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));
+    std::memset(&g.stats, 0, sizeof g.stats);
+    HIP_OK(hipEventElapsedTime(&g.stats.ms_extend, g.evA, g.evB));      // kernel time of this batch
     if (n) HIP_OK(hipMemcpy(out, dH.p, (size_t)n * sizeof(rdx_hit), hipMemcpyDeviceToHost));
     if (visit4) {
         unsigned long long v[8];

@@ -39,8 +39,10 @@ static_assert(sizeof(Material) == 48 && sizeof(MeshInfo) == 32 && sizeof(ScenePr
 
 // ---- derived device layout --------------------------------------------------------------------
 // stack / node references carry a 2-bit tag in the top bits
-enum : uint32_t { TAG_BLAS = 0u << 30, TAG_TLAS = 1u << 30, TAG_INST = 2u << 30, TAG_MASK = 3u << 30,
-                  IDX_MASK = ~(3u << 30) };
+enum : uint32_t { TAG_BLAS = 0u << 30, TAG_TLAS = 1u << 30, TAG_INST = 2u << 30, TAG_LEAF = 3u << 30, TAG_MASK = 3u << 30,
+                  IDX_MASK = ~(3u << 30),
+                  // TAG_LEAF work item: up to 8 consecutive triangle slots, (count-1) << 27 | first slot
+                  LEAF_START_BITS = 27, LEAF_START_MASK = (1u << 27) - 1u };
 
 struct alignas(16) DNode {        // 48 B; child / triangle indices are ABSOLUTE into the merged arrays
     float bmin[4];
@@ -52,11 +54,26 @@ struct alignas(16) DTri {         // 48 B: v0, e1 = v1 - v0, e2 = v2 - v0 (singl
     float e1[3]; uint32_t _p0;
     float e2[3]; uint32_t _p1;
 };
-struct alignas(16) DInst {        // 160 B
+struct alignas(16) DInst {        // 192 B
     float inv[16];                // InverseMat4x4(object->world), math.cl:56-183 evaluated once on the host
     float fwd[16];                // object->world
-    uint32_t SBTOffset, instanceID, customInstanceID, blasRoot;   // blasRoot: absolute node index
-    uint32_t _pad[4];
+    uint32_t SBTOffset, instanceID, customInstanceID, blasRoot;   // blasRoot: absolute DNode index (reference-order kernel)
+    uint32_t rootDesc0, rootDesc1, _p0, _p1;                      // root of the wide layout, encoded like a DWide child
+    float rootMin[4];             // root box (tested on entry iff the root is an inner node)
+    float rootMax[4];
 };
+
+// "Wide" BLAS node: one record per INNER node of the reference tree, carrying the boxes of BOTH
+// children, so a single 64-byte fetch decides both subtrees and leaf children need no node fetch at
+// all.  Child descriptor (d0, d1): inner child -> d0 = DWide index, d1 = 0;
+//                                  leaf child  -> d0 = first triangle slot, d1 = WIDE_LEAF | count.
+enum : uint32_t { WIDE_LEAF = 0x80000000u };
+struct alignas(16) DWide {        // 64 B
+    float lmin[3]; uint32_t ld0;
+    float lmax[3]; uint32_t ld1;
+    float rmin[3]; uint32_t rd0;
+    float rmax[3]; uint32_t rd1;
+};
+static_assert(sizeof(DWide) == 64 && sizeof(DInst) == 192, "derived layout");
 
 } // namespace rdx

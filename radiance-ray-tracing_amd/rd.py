@@ -315,14 +315,16 @@ PAYLOAD_DTYPE = np.dtype([("color", "<f4", 3), ("hit", "<u4"), ("nextFactor", "<
 assert HIT_DTYPE.itemsize == C.sizeof(_lib.rdx_hit) and PAYLOAD_DTYPE.itemsize == C.sizeof(_lib.rdx_payload)
 
 
-def TraceBatch(tlas, origins, dirs, tmin=0.001, tmax=1000.0, sbtRecordOffset=1, count_visits=False):
-    """Test seam: closest-hit (1) / any-hit (2) traversal of explicit rays -> structured array of HitData."""
+def TraceBatch(tlas, origins, dirs, tmin=0.001, tmax=1000.0, sbtRecordOffset=1, count_visits=False, reference_order=False):
+    """Test seam: closest-hit (1) / any-hit (2) traversal of explicit rays -> structured array of HitData.
+    Default = the production kernel; reference_order / count_visits use the reference-order kernel."""
     o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
     out = np.zeros(o.shape[0], HIT_DTYPE)
     visit = np.zeros(4, np.uint64)
+    mode = 1 if (reference_order or count_visits) else 0
     _check(_lib.lib().rdx_trace_batch(tlas.handle, o.ctypes.data, d.ctypes.data, o.shape[0], tmin, tmax,
-                                      sbtRecordOffset, out.ctypes.data, visit.ctypes.data if count_visits else None))
+                                      sbtRecordOffset, mode, out.ctypes.data, visit.ctypes.data if count_visits else None))
     return (out, visit) if count_visits else out
 
 

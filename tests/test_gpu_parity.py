@@ -75,16 +75,30 @@ def test_traversal_bit_exact(mods, name):
     assert blob == blob_o                                            # device blob == oracle blob
     osc = ob.OracleScene(s, blob_o)
     o, d = _ray_batch(osc, 4096, 5)
+    fields = ("distance", "primitiveIndex", "instanceIndex", "instanceCustomIndex", "instanceSBTOffset",
+              "barycentric", "hitPoint", "transform")
     for rec in (1, 2):
         ref, ctr = ob.trace_batch(blob_o, o, d, 0.001, 1000.0, rec, counters=True)
+        # reference-order kernel: everything bit-exact, including the visit counters
         got, visit = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, count_visits=True)
         assert np.array_equal(ref["hit"], got["hit"])
         h = ref["hit"] == 1
-        for f in ("distance", "primitiveIndex", "instanceIndex", "instanceCustomIndex", "instanceSBTOffset",
-                  "barycentric", "hitPoint", "transform"):
+        for f in fields:
             assert np.array_equal(_bits(ref[f][h]), _bits(got[f][h])), (rec, f)
         c = ctr.as_dict()
         assert list(visit) == [c["top_nodes"][rec - 1], c["inst_visits"][rec - 1], c["bot_nodes"][rec - 1], c["tri_tests"][rec - 1]]
+        # production kernels: 2 = wave-cooperative (default), 1 = per-lane wide nodes; both use the fast
+        # slab test and a free visiting order, and must still land on the reference's exact HitData
+        for kernel in (2, 1):
+            rd.SetOption("kernel", kernel)
+            try:
+                fast = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+            finally:
+                rd.SetOption("kernel", 2)
+            assert np.array_equal(ref["hit"], fast["hit"]), kernel
+            if rec == 1:        # a shadow ray only reports whether a candidate exists
+                for f in fields:
+                    assert np.array_equal(_bits(ref[f][h]), _bits(fast[f][h])), (kernel, f)
     assert h.sum() > 500      # the batch really exercises hits
 
 
@@ -96,6 +110,8 @@ def test_traversal_matches_committed_golden(mods):
         dev = scenes.DeviceScene(fn(**kw))
         got = rd.TraceBatch(dev.topAccelStruct, g[name + "_ray_o"], g[name + "_ray_d"])
         assert np.array_equal(_bits(got).reshape(got.shape[0], -1), g[name + "_hits"])
+        ro = rd.TraceBatch(dev.topAccelStruct, g[name + "_ray_o"], g[name + "_ray_d"], reference_order=True)
+        assert np.array_equal(_bits(ro).reshape(ro.shape[0], -1), g[name + "_hits"])
         sh = rd.TraceBatch(dev.topAccelStruct, g[name + "_ray_o"], g[name + "_ray_d"], sbtRecordOffset=2)
         assert np.array_equal(sh["hit"].astype(np.uint8), g[name + "_shadow_hit"])
 
