@@ -56,12 +56,12 @@ void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& p
                      uint32_t nPixels, uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples);
 // nPtr: device word holding the live count of this stage; nMax: upper bound used to size the grid
 void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,
-                   float tmin, float tmax, unsigned long long* visit);
+                   float tmin, float tmax, unsigned long long* visit, uint32_t* counter);
 void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
                   uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase);
 void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
                    uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,
-                   unsigned long long* visit);
+                   unsigned long long* visit, uint32_t* counter);
 void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* ownedPixels, uint32_t nPixels,
                        uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples, bool tonemap, uint32_t debug,
                        float* imageScratch, uint8_t* image);
@@ -72,7 +72,7 @@ void launch_pack_tiles(hipStream_t st, const uint8_t* image, uint8_t* packed, ui
 
 // test seams
 void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, const float* d, uint32_t n, float tmin,
-                        float tmax, int rec, rdx_hit* out, unsigned long long* visit, int mode);
+                        float tmax, int rec, rdx_hit* out, unsigned long long* visit, int mode, uint32_t* counter);
 void launch_material_batch(hipStream_t st, const SceneArgs& sc, const rdx_hit* hits, const float* dirs,
                            const uint32_t* pixels, const uint32_t* frames, const int32_t* depths, uint32_t n,
                            rdx_payload* out);

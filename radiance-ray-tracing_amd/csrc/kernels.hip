@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include "stages.h"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace rdx {
@@ -648,74 +649,92 @@ __device__ __forceinline__ void write_hit_record(const AccelView& A, const Trace
 
 
 // ---------------------------------------------------------------------------------------------
-// wave-cooperative extend / shadow (production): see traverse_coop.h
+// persistent wave-cooperative extend / shadow (production): see traverse_coop.h
 // ---------------------------------------------------------------------------------------------
+struct ExtendPolicy {
+    AccelView A; PathStreams ps;
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) const
+    {
+        const float4 ro = ps.rayO[i], rd = ps.rayD[i];
+        o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
+        return true;
+    }
+    __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const
+    {
+        ps.hitA[i] = make_float4(b.t, b.b1, b.b2, b.hit ? u2f(A.tris[b.slot].primID) : 0.0f);
+        ps.hitInst[i] = b.hit ? b.inst : RDX_MISS;
+    }
+};
+
+struct ShadowPolicy {
+    AccelView A; PathStreams ps; f3 Ldir; uint32_t lastBounce, nPixels, sampleBase;
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) const
+    {
+        const float4 so = ps.shO[i];
+        o = mk3(so.x, so.y, so.z); d = Ldir;
+        return ps.thrN[i].w != 0.0f;            // the closest-hit shader asked for a shadow query
+    }
+    __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const
+    {
+        // hit -> closest-hit row 2 `shadow` sets payload.hit; miss -> row 4 `shadowMiss` clears it
+        const float4 tn = ps.thrN[i];
+        bool occluded = false;
+        if (tn.w != 0.0f) {
+            Payload sp; sp.hit = false;
+            if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[b.inst].SBTOffset + 2, sp, hh, sv, Ldir, 0, 0, 0, false); }
+            else callMiss(4, sp);
+            occluded = sp.hit;
+        }
+        const float4 c = occluded ? ps.colSh[i] : ps.colLit[i];
+        const float4 no = ps.nextO[i], nd = ps.nextD[i];
+        if (lastBounce) { store_sample(ps, nPixels, sampleBase, f2u(no.w), f2u(nd.w), mk3(c.x, c.y, c.z)); return; }
+        const float4 so = ps.shO[i];
+        ps.rayO[i] = make_float4(no.x, no.y, no.z, so.w);
+        ps.rayD[i] = make_float4(nd.x, nd.y, nd.z, no.w);
+        ps.thr[i] = make_float4(tn.x, tn.y, tn.z, nd.w);
+        ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
+    }
+};
+
 __global__ void __launch_bounds__(RDX_BLOCK)
-k_extend_coop(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, float tmin, float tmax)
+k_extend_coop(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = *nPtr;
-    if (blockIdx.x * blockDim.x >= n) return;                  // whole block idle (block-uniform)
-    const bool active = i < n;
-    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (active) { ro = ps.rayO[i]; rd = ps.rayD[i]; }
-    Best b;
-    traverse_coop<1>(A, active, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax,
-                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed, b);
-    if (!active) return;
-    ps.hitA[i] = make_float4(b.t, b.b1, b.b2, b.hit ? u2f(A.tris[b.slot].primID) : 0.0f);
-    ps.hitInst[i] = b.hit ? b.inst : RDX_MISS;
+    ExtendPolicy pol{A, ps};
+    traverse_coop<1>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
 }
 
 __global__ void __launch_bounds__(RDX_BLOCK)
-k_shadow_coop(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t lastBounce,
-              uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
+k_shadow_coop(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
+              uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = *nPtr;
-    if (blockIdx.x * blockDim.x >= n) return;
-    bool active = i < n;
-    float4 so = make_float4(0.f, 0.f, 0.f, 0.f), tn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) { so = ps.shO[i]; tn = ps.thrN[i]; }
-    const bool wants = active && tn.w != 0.0f;
     const float* ld = sc.scene->lights[0].direction;
-    const f3 Ldir = normalize3(mk3(-ld[0], -ld[1], -ld[2]));     // shader.cl:471-476
-    Best b;
-    traverse_coop<2>(A, wants, mk3(so.x, so.y, so.z), Ldir, tmin, tmax,
-                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed, b);
-    if (!active) return;
-    bool occluded = false;
-    if (wants) {
-        Payload sp; sp.hit = false;
-        if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[b.inst].SBTOffset + 2, sp, hh, sv, Ldir, 0, 0, 0, false); }
-        else callMiss(4, sp);
-        occluded = sp.hit;
-    }
-    const float4 c = occluded ? ps.colSh[i] : ps.colLit[i];
-    const float4 no = ps.nextO[i], nd = ps.nextD[i];
-    if (lastBounce) { store_sample(ps, nPixels, sampleBase, f2u(no.w), f2u(nd.w), mk3(c.x, c.y, c.z)); return; }
-    ps.rayO[i] = make_float4(no.x, no.y, no.z, so.w);
-    ps.rayD[i] = make_float4(nd.x, nd.y, nd.z, no.w);
-    ps.thr[i] = make_float4(tn.x, tn.y, tn.z, nd.w);
-    ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
+    ShadowPolicy pol{A, ps, normalize3(mk3(-ld[0], -ld[1], -ld[2])), lastBounce, nPixels, sampleBase};   // shader.cl:471-476
+    traverse_coop<2>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
 }
+
+struct BatchPolicy {
+    AccelView A; const float* o; const float* d; rdx_hit* out;
+    __device__ __forceinline__ bool load(uint32_t i, f3& ro, f3& rd) const
+    {
+        ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        return true;
+    }
+    __device__ __forceinline__ void store(uint32_t i, const Best& b, f3 ro, f3 rd) const
+    {
+        TraceResult r;
+        r.t = b.t; r.b1 = b.b1; r.b2 = b.b2; r.inst = b.inst; r.hit = b.hit;
+        r.prim = b.hit ? A.tris[b.slot].primID : 0;
+        write_hit_record(A, r, ro, rd, out[i]);
+    }
+};
 
 template <int REC>
 __global__ void __launch_bounds__(RDX_BLOCK)
-k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, float tmin, float tmax,
-                   rdx_hit* __restrict__ out)
+k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
+                   float tmin, float tmax, rdx_hit* __restrict__ out)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < n;
-    f3 ro = mk3(0.f, 0.f, 0.f), rd = mk3(0.f, 0.f, 1.f);
-    if (active) { ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]); }
-    Best b;
-    traverse_coop<REC>(A, active, ro, rd, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed, b);
-    if (!active) return;
-    TraceResult r;
-    r.t = b.t; r.b1 = b.b1; r.b2 = b.b2; r.inst = b.inst; r.hit = b.hit;
-    r.prim = b.hit ? A.tris[b.slot].primID : 0;
-    write_hit_record(A, r, ro, rd, out[i]);
+    BatchPolicy pol{A, o, d, out};
+    traverse_coop<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,14 +843,20 @@ static inline uint32_t coop_threads(uint32_t need, size_t& ldsBytes)
     ldsBytes = perWave * (threads / 64);
     return threads;
 }
+// persistent grid: enough blocks to fill every CU at the LDS-limited residency, never more than the work
+static inline uint32_t coop_blocks(uint32_t nMax, uint32_t threads, size_t ldsBytes)
+{
+    const uint32_t perCU = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(ldsBytes, 1), 2048 / threads));
+    return std::min(blocks_for(nMax, threads), 256u * perCU);
+}
 
 void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,
-                   float tmin, float tmax, unsigned long long* visit)
+                   float tmin, float tmax, unsigned long long* visit, uint32_t* counter)
 {
     if (!nMax) return;
     if (!visit && av.kernel == 2) {
         size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
-        hipLaunchKernelGGL(k_extend_coop, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, ps, nPtr, tmin, tmax);
+        hipLaunchKernelGGL(k_extend_coop, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
         return;
     }
     size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);
@@ -851,12 +876,12 @@ void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
 
 void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
                    uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,
-                   unsigned long long* visit)
+                   unsigned long long* visit, uint32_t* counter)
 {
     if (!nMax) return;
     if (!visit && av.kernel == 2) {
         size_t ldsc; const uint32_t thc = coop_threads(av.stackNeed, ldsc);
-        hipLaunchKernelGGL(k_shadow_coop, dim3(blocks_for(nMax, thc)), dim3(thc), ldsc, st, av, sc, ps, nPtr,
+        hipLaunchKernelGGL(k_shadow_coop, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
                            lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
         return;
     }
@@ -896,13 +921,14 @@ void launch_pack_tiles(hipStream_t st, const uint8_t* image, uint8_t* packed, ui
 }
 
 void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, const float* d, uint32_t n, float tmin,
-                        float tmax, int rec, rdx_hit* out, unsigned long long* visit, int mode)
+                        float tmax, int rec, rdx_hit* out, unsigned long long* visit, int mode, uint32_t* counter)
 {
     if (!n) return;
     if (!visit && mode == 0 && av.kernel == 2) {
         size_t ldsc; const uint32_t thc = coop_threads(av.stackNeed, ldsc);
-        if (rec == 2) hipLaunchKernelGGL(k_trace_batch_coop<2>, dim3(blocks_for(n, thc)), dim3(thc), ldsc, st, av, o, d, n, tmin, tmax, out);
-        else hipLaunchKernelGGL(k_trace_batch_coop<1>, dim3(blocks_for(n, thc)), dim3(thc), ldsc, st, av, o, d, n, tmin, tmax, out);
+        const dim3 gc(coop_blocks(n, thc, ldsc));
+        if (rec == 2) hipLaunchKernelGGL(k_trace_batch_coop<2>, gc, dim3(thc), ldsc, st, av, o, d, n, counter, tmin, tmax, out);
+        else hipLaunchKernelGGL(k_trace_batch_coop<1>, gc, dim3(thc), ldsc, st, av, o, d, n, counter, tmin, tmax, out);
         return;
     }
     size_t lds; const uint32_t th = trav_threads(av.stackNeed, lds);

@@ -409,8 +409,8 @@ extern "C" int rdx_init(int device)
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&g.evA));
     HIP_OK(hipEventCreate(&g.evB));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dCounts), 64 * sizeof(uint32_t)));
-    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hCounts), 64 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dCounts), 256 * sizeof(uint32_t)));
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hCounts), 256 * sizeof(uint32_t), hipHostMallocDefault));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dVisit), 8 * sizeof(unsigned long long)));
     HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hVisit), 8 * sizeof(unsigned long long), hipHostMallocDefault));
     g.initialized = true;
@@ -758,9 +758,9 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         const uint32_t n0 = sc_n * P;
         const uint32_t sampleBase = rt.totalSamples + s0;
         // counts[0] = n0, counts[1..] = 0
-        std::memset(g.hCounts, 0, 64 * sizeof(uint32_t));
+        std::memset(g.hCounts, 0, 256 * sizeof(uint32_t));
         g.hCounts[0] = n0;
-        HIP_OK(hipMemcpyAsync(g.dCounts, g.hCounts, 64 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+        HIP_OK(hipMemcpyAsync(g.dCounts, g.hCounts, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
 
         g_timer.begin(&g.stats.ms_generate);
         launch_generate(g.stream, C, g.ps, owned, P, s0, sc_n, rt.totalSamples);
@@ -770,14 +770,15 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         }
         for (uint32_t d = 0; d < maxDepth; ++d) {
             g_timer.begin(&g.stats.ms_extend);
-            launch_extend(g.stream, av, g.ps, g.dCounts + d, n0, tmin, tmax, visit);
+            launch_extend(g.stream, av, g.ps, g.dCounts + d, n0, tmin, tmax, visit, g.dCounts + 64 + d);
             g_timer.end();
             g.stats.launches_extend++;
             g_timer.begin(&g.stats.ms_shade);
             launch_shade(g.stream, av, sc, g.ps, g.dCounts + d, g.dCounts + d + 1, n0, d, maxDepth, P, sampleBase);
             g_timer.end();
             g_timer.begin(&g.stats.ms_shadow);
-            launch_shadow(g.stream, av, sc, g.ps, g.dCounts + d + 1, n0, d + 1 == maxDepth, P, sampleBase, tmin, tmax, visit);
+            launch_shadow(g.stream, av, sc, g.ps, g.dCounts + d + 1, n0, d + 1 == maxDepth, P, sampleBase, tmin, tmax, visit,
+                          g.dCounts + 128 + d);
             g_timer.end();
             g.stats.launches_shadow++;
         }
@@ -785,7 +786,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         launch_accumulate(g.stream, g.ps, owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
                           static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
         g_timer.end();
-        HIP_OK(hipMemcpyAsync(g.hCounts, g.dCounts, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+        HIP_OK(hipMemcpyAsync(g.hCounts, g.dCounts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
         HIP_OK(hipStreamSynchronize(g.stream));
         if (maxDepth) g.stats.rays_primary += g.hCounts[0];
         for (uint32_t d = 1; d < maxDepth; ++d) g.stats.rays_bounce += g.hCounts[d];
@@ -834,8 +835,9 @@ extern "C" int rdx_trace_batch(rdx_buffer tlas, const float* o, const float* d, 
     DevArray<float> dO, dD; DevArray<rdx_hit> dH;
     HIP_OK(dO.upload(o, 3 * (size_t)n)); HIP_OK(dD.upload(d, 3 * (size_t)n)); HIP_OK(dH.alloc(n));
     if (visit4) HIP_OK(hipMemsetAsync(g.dVisit, 0, 8 * sizeof(unsigned long long), g.stream));
+    HIP_OK(hipMemsetAsync(g.dCounts + 64, 0, sizeof(uint32_t), g.stream));
     HIP_OK(hipEventRecord(g.evA, g.stream));
-    launch_trace_batch(g.stream, view_of(tlas), dO.p, dD.p, n, tmin, tmax, rec, dH.p, visit4 ? g.dVisit : nullptr, mode);
+    launch_trace_batch(g.stream, view_of(tlas), dO.p, dD.p, n, tmin, tmax, rec, dH.p, visit4 ? g.dVisit : nullptr, mode, g.dCounts + 64);
     HIP_OK(hipEventRecord(g.evB, g.stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));

@@ -1,4 +1,5 @@
-// traverse_coop.h -- wave-cooperative BVH traversal for wave64 (the production extend / shadow walk).
+// traverse_coop.h -- persistent, wave-cooperative BVH traversal for wave64 (the production extend /
+// shadow walk).
 //
 // Why this shape.  The reference's closest-hit walk (radiance/shader/radiance.cl:41-192) never culls
 // by the best t found so far: which nodes and triangles a ray visits depends on the slab tests alone.
@@ -10,36 +11,49 @@
 // A per-lane walk keeps only ~7-14 of 64 lanes busy on this workload (rocprofv3:
 // SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), because lanes drift apart between box tests,
 // triangle runs of different lengths and the early-outs of Möller–Trumbore.  Here a wave instead
-// alternates between two fully converged phases:
+// cycles through a few fully converged steps:
 //
 //   node step   every lane that holds a wide BLAS node does the same thing: one 64-byte fetch, two slab
 //               tests.  Leaf children are not tested in place: their triangle slots are appended to a
 //               per-wave queue in LDS (offsets from wave64 ballot prefix sums).
 //   test step   when >= 64 triangle tests are queued (or nothing else is left), each lane takes ONE
-//               queue entry -- possibly another lane's ray -- reads that ray's object-space origin /
+//               queue entry -- usually another lane's ray -- reads that ray's object-space origin /
 //               direction from LDS, runs a branch-free Möller–Trumbore with the reference's arithmetic
 //               and publishes an accepted candidate with a 64-bit LDS atomic-min on
-//               (t bits << 32 | instance slot << 22 | local triangle slot).
+//               (t bits << 32 | instance slot << 22 | BLAS-local triangle slot).
+//   top / instance steps   top-level nodes and instance entries.  Each lane keeps the object-space ray of
+//               its current AND previous instance in LDS (two slots, queue entries carry the slot bit), so
+//               a lane may run one instance ahead of its queued triangle tests.
+//   Which step runs next is greedy: the kind the most lanes are waiting for, so waiting lanes batch up
+//   and every step executes as converged as the moment allows.
+//   refill step the wave is persistent: a lane whose ray is finished (stack empty and all its queued
+//               tests consumed) writes its result and pulls the next ray index from a global counter
+//               (one wave-aggregated atomic per refill), so lanes do not idle while a long ray of the
+//               same wave is still walking.  The wave leaves when the counter is exhausted, every lane
+//               is idle and the queue is empty -- an exit every wave reaches.
 //
-// Top-level nodes and instance entries are rare and handled when no lane holds a BLAS node; the
-// queue is drained before any lane switches instance, so a queued entry always refers to its owner's
-// current object-space ray.  Any-hit (shadow) rays use the same machinery and drop their remaining
-// work as soon as a candidate has been published.
+// Any-hit (shadow) rays use the same machinery and drop their remaining work as soon as a candidate
+// has been published.
 //
 // Limits (checked on the host, otherwise the per-lane kernels are used): <= 1024 instances,
-// <= 4M triangles per BLAS, < 64M triangle slots in total.
+// <= 4M triangles per BLAS, < 32M triangle slots in total.
 #pragma once
 
 namespace rdx {
 
 #define COOP_QCAP 512u                 // queue ring capacity in entries (power of two)
-#define COOP_LANE_SHIFT 26u            // queue entry = owner lane << 26 | absolute triangle slot
-#define COOP_SLOT_MASK ((1u << 26) - 1u)
+#define COOP_LANE_SHIFT 26u            // queue entry = owner lane << 26 | ray-slot bit << 25 | absolute triangle slot
+#define COOP_PAR_SHIFT 25u
+#define COOP_SLOT_MASK ((1u << 25) - 1u)
 #define COOP_INST_SHIFT 22u            // key low word = instance slot << 22 | BLAS-local triangle slot
 #define COOP_LOCAL_MASK ((1u << 22) - 1u)
 #define COOP_NONE 0xffffffffu
+#define COOP_RAY_WORDS 8u              // per lane per slot: o.xyz d.xyz instance triBase
+#ifndef COOP_IDLE_BIAS
+#define COOP_IDLE_BIAS 16              // a refill step needs this many more idle lanes than the busiest work kind has (tuned: profiles/)
+#endif
 
-__host__ __device__ inline uint32_t coop_words_per_wave(uint32_t need) { return need * 64u + COOP_QCAP + 6u * 64u + 64u + 64u + 128u; }
+__host__ __device__ inline uint32_t coop_words_per_wave(uint32_t need) { return need * 64u + COOP_QCAP + 2u * COOP_RAY_WORDS * 64u + 128u; }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
 {
@@ -47,11 +61,9 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
 }
 
 struct CoopLds {
-    uint32_t* stack;                 // [need][64]
+    uint32_t* stack;                 // [need][64]   (already offset by the lane)
     uint32_t* queue;                 // [COOP_QCAP]
-    float* ray;                      // [6][64] object-space origin.xyz, direction.xyz of each lane's current instance
-    uint32_t* inst;                  // [64] current instance slot
-    uint32_t* base;                  // [64] first triangle slot of the current BLAS
+    float* ray;                      // [2 slots][8 words][64 lanes]
     unsigned long long* best;        // [64]
 };
 
@@ -74,7 +86,7 @@ __device__ __forceinline__ bool coop_triangle(const AccelView& A, uint32_t slot,
     return (det != 0) & !(b1 < 0 || b1 > 1) & !(b2 < 0 || b1 + b2 > 1) & (t > 0) & (t > tmin) & (t < tmax);
 }
 
-// one test step: up to 64 queued (owner, triangle) pairs, one per lane
+// one test step: up to 64 queued (owner ray slot, triangle) pairs, one per lane
 __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t& qHead,
                                                uint32_t qTail, float tmin, float tmax)
 {
@@ -82,11 +94,12 @@ __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds
     if (lane < n) {
         const uint32_t e = L.queue[(qHead + lane) & (COOP_QCAP - 1u)];
         const uint32_t owner = e >> COOP_LANE_SHIFT, slot = e & COOP_SLOT_MASK;
-        const f3 ro = mk3(L.ray[0 * 64 + owner], L.ray[1 * 64 + owner], L.ray[2 * 64 + owner]);
-        const f3 rd = mk3(L.ray[3 * 64 + owner], L.ray[4 * 64 + owner], L.ray[5 * 64 + owner]);
+        const float* rs = L.ray + ((e >> COOP_PAR_SHIFT) & 1u) * (COOP_RAY_WORDS * 64u) + owner;
+        const f3 ro = mk3(rs[0 * 64], rs[1 * 64], rs[2 * 64]);
+        const f3 rd = mk3(rs[3 * 64], rs[4 * 64], rs[5 * 64]);
         float t, b1, b2;
         if (coop_triangle(A, slot, ro, rd, tmin, tmax, t, b1, b2)) {
-            const uint32_t low = (L.inst[owner] << COOP_INST_SHIFT) | (slot - L.base[owner]);
+            const uint32_t low = (__float_as_uint(rs[6 * 64]) << COOP_INST_SHIFT) | (slot - __float_as_uint(rs[7 * 64]));
             const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;
             atomicMin(&L.best[owner], key);
         }
@@ -95,8 +108,8 @@ __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds
 }
 
 // append `cnt` (0..8) consecutive triangle slots starting at `start` for every lane; wave-uniform control
-__device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t cnt, uint32_t start,
-                                             uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
+__device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t tagBits, uint32_t cnt,
+                                             uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
 {
     uint32_t pre = 0, total = 0;
 #pragma unroll
@@ -108,38 +121,176 @@ __device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& 
     if (total == 0) return;
     while (qTail - qHead + total > COOP_QCAP) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
     const uint32_t at = qTail + pre;
-    for (uint32_t k = 0; k < cnt; ++k) L.queue[(at + k) & (COOP_QCAP - 1u)] = (lane << COOP_LANE_SHIFT) | (start + k);
+    for (uint32_t k = 0; k < cnt; ++k) L.queue[(at + k) & (COOP_QCAP - 1u)] = tagBits | (start + k);
     qTail += total;
 }
 
-// All 64 lanes of the wave call this (inactive lanes pass active = false).
-template <int REC>
-__device__ __forceinline__ void traverse_coop(const AccelView& A, bool active, f3 o, f3 d, float tmin, float tmax,
-                                              uint32_t* __restrict__ lds, uint32_t need, Best& B)
+// Ray source / result sink of one use of the walk (extend, shadow, test batch):
+//   bool load(uint32_t i, f3& o, f3& d)      -- false: this ray needs no traversal (finalised with a miss)
+//   void store(uint32_t i, const Best& b, f3 o, f3 d)
+//
+// All 64 lanes of the wave call this; `counter` is a zero-initialised device word shared by the grid.
+template <int REC, class Policy>
+__device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
+                                              float tmin, float tmax, uint32_t* __restrict__ lds, uint32_t need)
 {
     const uint32_t lane = __lane_id();
     CoopLds L;
     L.stack = lds + lane;                                  // [level * 64]
     L.queue = lds + need * 64u;
     L.ray = reinterpret_cast<float*>(L.queue + COOP_QCAP);
-    L.inst = reinterpret_cast<uint32_t*>(L.ray + 6 * 64);
-    L.base = L.inst + 64;
-    L.best = reinterpret_cast<unsigned long long*>(L.base + 64);
-    L.best[lane] = ~0ull;
-    L.inst[lane] = 0; L.base[lane] = 0;
+    L.best = reinterpret_cast<unsigned long long*>(L.ray + 2u * COOP_RAY_WORDS * 64u);
 
-    uint32_t qHead = 0, qTail = 0;                         // wave-uniform
-    uint32_t sp = 0;
-    uint32_t cur = active ? (TAG_TLAS | 0u) : COOP_NONE;
+    uint32_t qHead = 0, qTail = 0;                         // wave-uniform, monotonically increasing
+    bool exhausted = false;                                // wave-uniform: the global counter ran past n
+    // per-lane ray state
+    uint32_t rayIdx = COOP_NONE;                           // ray being walked (COOP_NONE: lane is free)
+    uint32_t cur = COOP_NONE, sp = 0;
+    uint32_t par = 0;                                      // LDS ray slot of the current instance
+    uint32_t markPrev = 0;                                 // qTail when the previous instance was left
+    uint32_t finMark = 0; bool finishing = false;
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     RayInst R;
     R.o = o; R.d = d; R.rcp = mk3(0.f, 0.f, 0.f); R.exactOnly = true;
 
 #define COOP_POP() do { if (sp == 0) cur = COOP_NONE; else { --sp; cur = L.stack[sp * 64u]; } } while (0)
 
     for (;;) {
-        const bool isNode = (cur != COOP_NONE) && ((cur & TAG_MASK) == TAG_BLAS);
-        if (__any(isNode)) {
-            // ---- node step ------------------------------------------------------------------------
+        // ---- lanes whose walk has ended wait for their queued tests, then hand the result over ----
+        if (rayIdx != COOP_NONE && cur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }
+        const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
+        const bool isFree = (rayIdx == COOP_NONE);
+        const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
+        const unsigned long long workMask = __ballot(cur != COOP_NONE);
+        const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
+        // Step selection is greedy: of the step kinds that lanes are waiting for (refill, top-level node,
+        // instance entry, BLAS node) the wave takes the one with the most lanes, so every step runs as
+        // converged as the moment allows and waiting lanes batch up instead of trickling through.
+        const uint32_t tag = cur & TAG_MASK;
+        const bool has = (cur != COOP_NONE);
+        const bool isNode = has && tag == TAG_BLAS, isLeaf = has && tag == TAG_LEAF, isTop = has && tag == TAG_TLAS,
+                   isInst = has && tag == TAG_INST;
+        const unsigned long long nodeMask = __ballot(isNode), topMask = __ballot(isTop), instMask = __ballot(isInst);
+        const int nNode = __popcll(nodeMask), nTop = __popcll(topMask), nInst = __popcll(instMask);
+        const int nMaxWork = max(nNode, max(nTop, nInst));
+        if (nIdle > 0 && (nIdle >= nMaxWork + COOP_IDLE_BIAS || workMask == 0ull)) {
+            if (done) {
+                Best B;
+                B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
+                const unsigned long long key = L.best[lane];
+                if (key != ~0ull) {
+                    const uint32_t low = (uint32_t)key;
+                    const uint32_t inst = low >> COOP_INST_SHIFT;
+                    const DInst& I = A.insts[inst];
+                    B.slot = I._p0 + (low & COOP_LOCAL_MASK);
+                    B.hit = true; B.inst = inst;
+                    B.t = __uint_as_float((uint32_t)(key >> 32));
+                    if (REC == 1) {      // b1 / b2 recomputed with the arithmetic of the accepting test
+                        const f3 ro = mat4_mul3(I.inv, o.x, o.y, o.z, 1.0f);
+                        const f3 rd = mat4_mul3(I.inv, d.x, d.y, d.z, 0.0f);
+                        float t, b1, b2;
+                        coop_triangle(A, B.slot, ro, rd, tmin, tmax, t, b1, b2);
+                        B.t = t; B.b1 = b1; B.b2 = b2;
+                    }
+                }
+                pol.store(rayIdx, B, o, d);
+                rayIdx = COOP_NONE; finishing = false;
+            }
+            if (!exhausted) {
+                const bool want = (rayIdx == COOP_NONE);
+                const unsigned long long wm = __ballot(want);
+                const uint32_t cnt = (uint32_t)__popcll(wm);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(counter, cnt);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + cnt >= n) exhausted = true;
+                if (want) {
+                    const uint32_t idx = base + lanes_below(wm);
+                    if (idx < n) {
+                        rayIdx = idx;
+                        L.best[lane] = ~0ull;
+                        sp = 0; par = 0; markPrev = qHead; finishing = false;
+                        const bool walk = pol.load(idx, o, d);
+                        cur = walk ? (TAG_TLAS | 0u) : COOP_NONE;
+                    }
+                }
+            }
+            continue;
+        }
+        if (workMask == 0ull) {
+            if (qTail != qHead) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
+            if (__ballot(rayIdx != COOP_NONE) == 0ull) break;      // exhausted, every lane free, queue empty
+            continue;                                              // lanes still finishing: next round hands them over
+        }
+
+        // ---- queued piece of an oversized leaf, or a leaf root ----------------------------------------
+        if (__any(isLeaf)) {
+            uint32_t cnt = 0, st = 0;
+            if (isLeaf) { st = cur & LEAF_START_MASK; cnt = ((cur >> LEAF_START_BITS) & 7u) + 1u; COOP_POP(); }
+            coop_enqueue(A, L, lane, (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT), cnt, st, qHead, qTail, tmin, tmax);
+            continue;
+        }
+        // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------
+        if (nTop > 0 && nTop >= nNode && nTop >= nInst) {
+            if (isTop) {
+                const float4* np = reinterpret_cast<const float4*>(A.tnodes + (cur & IDX_MASK));
+                const float4 bmin = np[0], bmax = np[1];
+                const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
+                if (!(w.x & LEAF_BIT)) {
+                    if (slab_hit(o, d, bmin, bmax)) { L.stack[sp * 64u] = TAG_TLAS | w.y; ++sp; cur = TAG_TLAS | w.x; }
+                    else COOP_POP();
+                } else {
+                    const uint32_t count = w.x & 0x7fffffffu;
+                    if (w.z == TYPE_INST && count > 0) {
+                        for (uint32_t i = count - 1; i >= 1; --i) { L.stack[sp * 64u] = TAG_INST | (w.y + i); ++sp; }
+                        cur = TAG_INST | w.y;
+                    } else COOP_POP();
+                }
+            }
+            continue;
+        }
+        // ---- instance entry (radiance.cl:161-169) ----------------------------------------------------------
+        if (nInst > 0 && nInst >= nNode) {
+            // the LDS ray slot about to be overwritten belongs to the instance before the previous one:
+            // every queued test of it lies before markPrev
+            const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
+            if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
+            if (REC == 2) { if (ready && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+            if (ready && cur != COOP_NONE) {
+                const uint32_t ci = cur & IDX_MASK;
+                const float4* ip = reinterpret_cast<const float4*>(A.insts + ci);
+                float m[16];
+                *reinterpret_cast<float4*>(m + 0) = ip[0];
+                *reinterpret_cast<float4*>(m + 4) = ip[1];
+                *reinterpret_cast<float4*>(m + 8) = ip[2];
+                *reinterpret_cast<float4*>(m + 12) = ip[3];
+                R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
+                R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
+                R.rcp = mk3(1.0f / R.d.x, 1.0f / R.d.y, 1.0f / R.d.z);
+                const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
+                const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
+                R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
+                const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
+                markPrev = qTail;            // everything queued so far belongs to instances being left
+                par ^= 1u;
+                float* rs = L.ray + par * (COOP_RAY_WORDS * 64u) + lane;
+                rs[0 * 64] = R.o.x; rs[1 * 64] = R.o.y; rs[2 * 64] = R.o.z;
+                rs[3 * 64] = R.d.x; rs[4 * 64] = R.d.y; rs[5 * 64] = R.d.z;
+                rs[6 * 64] = __uint_as_float(ci); rs[7 * 64] = __uint_as_float(rdsc.z);
+                if (rdsc.y & WIDE_LEAF) {
+                    uint32_t cnt = rdsc.y & 0x7fffffffu, st = rdsc.x;
+                    while (cnt > 8u) { L.stack[sp * 64u] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }
+                    if (cnt) cur = leaf_item(st, cnt); else COOP_POP();
+                } else {
+                    const float4 rmin = ip[10], rmax = ip[11];
+                    if (slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z))) cur = rdsc.x;
+                    else COOP_POP();
+                }
+            }
+            continue;
+        }
+        // ---- node step ----------------------------------------------------------------------------------------
+        if (nodeMask != 0ull) {
             uint32_t cntL = 0, stL = 0, cntR = 0, stR = 0, nextL = COOP_NONE, nextR = COOP_NONE;
             if (isNode) {
                 const float4* wp = reinterpret_cast<const float4*>(A.wide + (cur & IDX_MASK));
@@ -162,103 +313,19 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, bool active, f
                 else if (nextR != COOP_NONE) cur = nextR;
                 else COOP_POP();
             }
-            coop_enqueue(A, L, lane, cntL, stL, qHead, qTail, tmin, tmax);
-            coop_enqueue(A, L, lane, cntR, stR, qHead, qTail, tmin, tmax);
+            const uint32_t tagBits = (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT);
+            coop_enqueue(A, L, lane, tagBits, cntL, stL, qHead, qTail, tmin, tmax);
+            coop_enqueue(A, L, lane, tagBits, cntR, stR, qHead, qTail, tmin, tmax);
             if (qTail - qHead >= 64u) {
                 coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
                 if (REC == 2) { if (cur != COOP_NONE && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
             }
             continue;
         }
-        const uint32_t tag = cur & TAG_MASK;
-        const bool isLeaf = (cur != COOP_NONE) && tag == TAG_LEAF;
-        if (__any(isLeaf)) {
-            // ---- queued piece of an oversized leaf, or a leaf root -----------------------------------
-            uint32_t cnt = 0, st = 0;
-            if (isLeaf) { st = cur & LEAF_START_MASK; cnt = ((cur >> LEAF_START_BITS) & 7u) + 1u; COOP_POP(); }
-            coop_enqueue(A, L, lane, cnt, st, qHead, qTail, tmin, tmax);
-            continue;
-        }
-        const bool isTop = (cur != COOP_NONE) && tag == TAG_TLAS;
-        if (__any(isTop)) {
-            // ---- top-level node (radiance.cl:110-150) --------------------------------------------------
-            if (isTop) {
-                const float4* np = reinterpret_cast<const float4*>(A.tnodes + (cur & IDX_MASK));
-                const float4 bmin = np[0], bmax = np[1];
-                const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
-                if (!(w.x & LEAF_BIT)) {
-                    if (slab_hit(o, d, bmin, bmax)) { L.stack[sp * 64u] = TAG_TLAS | w.y; ++sp; cur = TAG_TLAS | w.x; }
-                    else COOP_POP();
-                } else {
-                    const uint32_t count = w.x & 0x7fffffffu;
-                    if (w.z == TYPE_INST && count > 0) {
-                        for (uint32_t i = count - 1; i >= 1; --i) { L.stack[sp * 64u] = TAG_INST | (w.y + i); ++sp; }
-                        cur = TAG_INST | w.y;
-                    } else COOP_POP();
-                }
-            }
-            continue;
-        }
-        const bool isInst = (cur != COOP_NONE);                 // only TAG_INST items are left
-        if (__any(isInst)) {
-            // ---- instance entry: drain first, every queued entry refers to its owner's CURRENT instance ----
-            while (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
-            if (REC == 2) { if (cur != COOP_NONE && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
-            if (cur != COOP_NONE) {
-                const uint32_t ci = cur & IDX_MASK;
-                const float4* ip = reinterpret_cast<const float4*>(A.insts + ci);
-                float m[16];
-                *reinterpret_cast<float4*>(m + 0) = ip[0];
-                *reinterpret_cast<float4*>(m + 4) = ip[1];
-                *reinterpret_cast<float4*>(m + 8) = ip[2];
-                *reinterpret_cast<float4*>(m + 12) = ip[3];
-                R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);         // radiance.cl:161-169
-                R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
-                R.rcp = mk3(1.0f / R.d.x, 1.0f / R.d.y, 1.0f / R.d.z);
-                const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
-                const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
-                R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
-                L.ray[0 * 64 + lane] = R.o.x; L.ray[1 * 64 + lane] = R.o.y; L.ray[2 * 64 + lane] = R.o.z;
-                L.ray[3 * 64 + lane] = R.d.x; L.ray[4 * 64 + lane] = R.d.y; L.ray[5 * 64 + lane] = R.d.z;
-                const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
-                L.inst[lane] = ci; L.base[lane] = rdsc.z;
-                if (rdsc.y & WIDE_LEAF) {
-                    uint32_t cnt = rdsc.y & 0x7fffffffu, st = rdsc.x;
-                    while (cnt > 8u) { L.stack[sp * 64u] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }
-                    if (cnt) cur = leaf_item(st, cnt); else COOP_POP();
-                } else {
-                    const float4 rmin = ip[10], rmax = ip[11];
-                    if (slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z))) cur = rdsc.x;
-                    else COOP_POP();
-                }
-            }
-            continue;
-        }
-        // ---- nobody holds a work item: finish the queue and leave ----------------------------------------
-        while (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
-        break;
+        // lanes are waiting below their thresholds and nothing else can run: let the queue advance
+        if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
     }
 #undef COOP_POP
-
-    // ---- decode the winner; b1 / b2 are recomputed with the arithmetic of the accepting test ------------
-    B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
-    const unsigned long long key = L.best[lane];
-    if (active && key != ~0ull) {
-        const uint32_t low = (uint32_t)key;
-        const uint32_t inst = low >> COOP_INST_SHIFT;
-        const DInst& I = A.insts[inst];
-        const uint32_t slot = I._p0 + (low & COOP_LOCAL_MASK);
-        B.hit = true; B.inst = inst; B.slot = slot;
-        if (REC == 1) {
-            const f3 ro = mat4_mul3(I.inv, o.x, o.y, o.z, 1.0f);
-            const f3 rd = mat4_mul3(I.inv, d.x, d.y, d.z, 0.0f);
-            float t, b1, b2;
-            coop_triangle(A, slot, ro, rd, tmin, tmax, t, b1, b2);
-            B.t = t; B.b1 = b1; B.b2 = b2;
-        } else {
-            B.t = __uint_as_float((uint32_t)(key >> 32));
-        }
-    }
 }
 
 } // namespace rdx
