@@ -243,6 +243,32 @@ int derive_accel(rdx_buffer_s* tb)
         d.blasRoot = it->second.nodeBase;
         d.rootDesc0 = it->second.rootDesc0; d.rootDesc1 = it->second.rootDesc1; d._p0 = it->second.triBase;
         for (int k = 0; k < 3; ++k) { d.rootMin[k] = it->second.rootMin[k]; d.rootMax[k] = it->second.rootMax[k]; }
+        // conservative world-space box of the root OBB + margin coefficient for the instance pre-test
+        {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, fa = 0, fi = 0;
+            bool finite = true;
+            for (int c = 0; c < 8; ++c) {
+                const double p[3] = {(c & 1) ? d.rootMax[0] : d.rootMin[0], (c & 2) ? d.rootMax[1] : d.rootMin[1], (c & 4) ? d.rootMax[2] : d.rootMin[2]};
+                for (int r = 0; r < 3; ++r) {
+                    const double w = (double)bi.m[4 * r] * p[0] + (double)bi.m[4 * r + 1] * p[1] + (double)bi.m[4 * r + 2] * p[2] + (double)bi.m[4 * r + 3];
+                    lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
+                    finite = finite && std::isfinite(w);
+                }
+            }
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { fa += (double)bi.m[4 * r + c] * bi.m[4 * r + c]; fi += (double)d.inv[4 * r + c] * d.inv[4 * r + c]; }
+            const bool affine = bi.m[12] == 0.f && bi.m[13] == 0.f && bi.m[14] == 0.f && bi.m[15] == 1.f;
+            const double kappa = std::sqrt(fa) * std::sqrt(fi);
+            const bool usable = finite && affine && !(d.rootDesc1 & WIDE_LEAF) && kappa > 0 && kappa < 1e4 && std::isfinite(kappa);
+            double ext = 0;
+            for (int r = 0; r < 3; ++r) {
+                d.worldMin[r] = std::nextafterf((float)lo[r], -INFINITY); d.worldMax[r] = std::nextafterf((float)hi[r], INFINITY);
+                ext = std::max(ext, std::max(std::fabs(lo[r]), std::fabs(hi[r])));
+            }
+            // margin = c * (|o|_inf + ext): 64 x the first-order bound 4u*kappa on the displacement of the
+            // object-space ray the reference builds in fp32 (DESIGN.md "instance pre-test")
+            d.worldMin[3] = usable ? (float)(64.0 * 5.97e-8 * 4.0 * kappa) : -1.0f;
+            d.worldMax[3] = (float)ext;
+        }
     }
     // stack need: TLAS part
     std::vector<uint32_t> needT(nTop, 0);

@@ -54,13 +54,17 @@ struct alignas(16) DTri {         // 48 B: v0, e1 = v1 - v0, e2 = v2 - v0 (singl
     float e1[3]; uint32_t _p0;
     float e2[3]; uint32_t _p1;
 };
-struct alignas(16) DInst {        // 192 B
+struct alignas(16) DInst {        // 224 B
     float inv[16];                // InverseMat4x4(object->world), math.cl:56-183 evaluated once on the host
     float fwd[16];                // object->world
     uint32_t SBTOffset, instanceID, customInstanceID, blasRoot;   // blasRoot: absolute DNode index (reference-order kernel)
     uint32_t rootDesc0, rootDesc1, _p0, _p1;                      // root of the wide layout, encoded like a DWide child
     float rootMin[4];             // root box (tested on entry iff the root is an inner node)
     float rootMax[4];
+    // world-space AABB of the root box for the conservative instance pre-test (traverse_coop.h):
+    // worldMin[3] = margin coefficient c (< 0: no pre-test for this instance), worldMax[3] = max |coordinate|
+    float worldMin[4];
+    float worldMax[4];
 };
 
 // "Wide" BLAS node: one record per INNER node of the reference tree, carrying the boxes of BOTH
@@ -74,6 +78,6 @@ struct alignas(16) DWide {        // 64 B
     float rmin[3]; uint32_t rd0;
     float rmax[3]; uint32_t rd1;
 };
-static_assert(sizeof(DWide) == 64 && sizeof(DInst) == 192, "derived layout");
+static_assert(sizeof(DWide) == 64 && sizeof(DInst) == 224, "derived layout");
 
 } // namespace rdx

@@ -125,6 +125,24 @@ __device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& 
     qTail += total;
 }
 
+// Conservative world-space rejection of an instance whose BLAS root is an inner node.  The reference
+// would transform the ray and slab-test the root box in object space (radiance.cl:161-176, 61-63); if the
+// world ray misses the world AABB of that box, grown by a margin that dominates every fp32 rounding the
+// reference's own computation can incur, that test is known to fail and the instance entry
+// can be skipped without changing any result.  Returns true when the instance must be entered.
+__device__ __forceinline__ bool coop_inst_pretest(const DInst& I, f3 o, f3 rcpW, float oMax, bool preOK)
+{
+    const float4 wmin = *reinterpret_cast<const float4*>(I.worldMin), wmax = *reinterpret_cast<const float4*>(I.worldMax);
+    if (!preOK || !(wmin.w >= 0.0f)) return true;
+    const float m = wmin.w * (oMax + wmax.w);
+    const f3 tA = (mk3(wmin.x - m, wmin.y - m, wmin.z - m) - o) * rcpW, tB = (mk3(wmax.x + m, wmax.y + m, wmax.z + m) - o) * rcpW;
+    const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
+    const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
+    const float n0 = fmaxf(tNear, 0.0f);
+    const float band = 4.8e-7f * (fabsf(tFar) + n0) + 1e-30f;
+    return !((tFar - n0) < -band);          // NaN / inf fall through to "enter"
+}
+
 // Ray source / result sink of one use of the walk (extend, shadow, test batch):
 //   bool load(uint32_t i, f3& o, f3& d)      -- false: this ray needs no traversal (finalised with a miss)
 //   void store(uint32_t i, const Best& b, f3 o, f3 d)
@@ -150,6 +168,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     uint32_t markPrev = 0;                                 // qTail when the previous instance was left
     uint32_t finMark = 0; bool finishing = false;
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+    f3 rcpW = mk3(0.f, 0.f, 0.f); bool preOK = false; float oMax = 0.f;   // world-space pre-test state
     RayInst R;
     R.o = o; R.d = d; R.rcp = mk3(0.f, 0.f, 0.f); R.exactOnly = true;
 
@@ -212,6 +231,11 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                         sp = 0; par = 0; markPrev = qHead; finishing = false;
                         const bool walk = pol.load(idx, o, d);
                         cur = walk ? (TAG_TLAS | 0u) : COOP_NONE;
+                        rcpW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        const float amin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+                        const float amax = fmaxf(fmaxf(fabsf(rcpW.x), fabsf(rcpW.y)), fabsf(rcpW.z));
+                        oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+                        preOK = (amin > 1e-20f) && (amax < 1e20f) && (oMax < 1e20f);
                     }
                 }
             }
@@ -241,10 +265,13 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                     else COOP_POP();
                 } else {
                     const uint32_t count = w.x & 0x7fffffffu;
-                    if (w.z == TYPE_INST && count > 0) {
-                        for (uint32_t i = count - 1; i >= 1; --i) { L.stack[sp * 64u] = TAG_INST | (w.y + i); ++sp; }
-                        cur = TAG_INST | w.y;
-                    } else COOP_POP();
+                    if (w.z == TYPE_INST) {
+                        // every instance of the leaf is entered by the reference (no per-instance box test);
+                        // instances whose root box the ray provably misses are dropped here (coop_inst_pretest)
+                        for (uint32_t i = count; i-- > 0;)
+                            if (coop_inst_pretest(A.insts[w.y + i], o, rcpW, oMax, preOK)) { L.stack[sp * 64u] = TAG_INST | (w.y + i); ++sp; }
+                    }
+                    COOP_POP();
                 }
             }
             continue;

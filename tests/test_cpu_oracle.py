@@ -220,3 +220,25 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"liboracle|oracle_bind|orc_[a-z]+\(|oracle/", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def _build_cpp_sample(tmp_path):
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "cornell_rd")
+    lib_dir = os.path.join(ROOT, "radiance-ray-tracing_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "samples", "cornell_rd.cpp"),
+                           "-L" + lib_dir, "-lrdx", "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_cpp_facade_sample_links_and_fails_loudly_without_gpu(pkg, tmp_path):
+    """the RD:: facade (include/radiance.h) compiles and links against librdx.so like the reference's
+    sample1.cpp would; without a device it ends with the reference's policy: message + exit(-1)"""
+    import torch
+    exe = _build_cpp_sample(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu suite")
+    r = subprocess.run([exe, "32", "18", "1", str(tmp_path / "o.ppm")], capture_output=True, text=True)
+    assert r.returncode == 255 and "Radiance Error" in r.stdout
