@@ -438,7 +438,10 @@ __device__ __forceinline__ void fill_hit_info(const AccelView& A, uint32_t instS
     h.fwd = I.fwd;
 }
 
-__global__ void __launch_bounds__(RDX_BLOCK)
+#ifndef RDX_SHADE_WAVES
+#define RDX_SHADE_WAVES 1
+#endif
+__global__ void __launch_bounds__(RDX_BLOCK, RDX_SHADE_WAVES)
 k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ nOut,
         uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
 {

@@ -67,7 +67,10 @@ __device__ inline f3 f_schlick(float cosTheta, float metallic, f3 albedo)   // p
 {
     const f3 lo = mk3(0.04f, 0.04f, 0.04f);
     f3 F0 = lo + (albedo - lo) * metallic;
-    float p = powf(1.0f - cosTheta, 5.0f);
+    // pow(1 - cosTheta, 5): cosTheta is clamped to [0,1], so the base is in [0,1] and the product chain
+    // is within ~2 ulp of a correctly rounded pow (the oracle's powf and OCML's differ by as much)
+    const float x = 1.0f - cosTheta, x2 = x * x;
+    const float p = x2 * x2 * x;
     return F0 + one_minus(F0) * p;
 }
 
@@ -84,14 +87,21 @@ __device__ inline float smith_lambda(f3 w, float a)   // pbr.cl:41-74 Lambda and
     return (sqrtf(1.0f + alpha2 * tan2) - 1.0f) / 2.0f;
 }
 
-__device__ inline float g_pbrt(f3 wo, f3 wi, f3 n, float roughness)   // pbr.cl:77-96
+// Tangent frame of a normal and its 4x4 inverse.  The reference rebuilds both inside every G_pbrt call
+// and every sampled direction (pbr.cl:87-88, 309-311, 339-341, 362-364); for one hit they are the same
+// matrices, so they are built once here and reused -- same values, fewer instructions.
+struct NFrame { float tbn[16]; float inv[16]; };
+__device__ inline void make_frame(f3 n, NFrame& F)
 {
-    float tbn[16], inv[16];
-    for (int i = 0; i < 16; ++i) inv[i] = 0.0f;   // reference: uninitialised if det == 0
-    normal_space(n, tbn);
-    inverse_mat4(tbn, inv);
-    f4 lo = mat4_mul(inv, wo.x, wo.y, wo.z, 0.0f);
-    f4 li = mat4_mul(inv, wi.x, wi.y, wi.z, 0.0f);
+    normal_space(n, F.tbn);
+    for (int i = 0; i < 16; ++i) F.inv[i] = 0.0f;      // reference: uninitialised if det == 0
+    inverse_mat4(F.tbn, F.inv);
+}
+
+__device__ inline float g_pbrt(const NFrame& F, f3 wo, f3 wi, float roughness)   // pbr.cl:77-96
+{
+    f4 lo = mat4_mul(F.inv, wo.x, wo.y, wo.z, 0.0f);
+    f4 li = mat4_mul(F.inv, wi.x, wi.y, wi.z, 0.0f);
     if (li.z < 0 || lo.z < 0) return 0.0f;
     return 1 / (1 + smith_lambda(mk3(li.x, li.y, li.z), roughness) + smith_lambda(mk3(lo.x, lo.y, lo.z), roughness));
 }
@@ -108,7 +118,8 @@ __device__ inline f3 refract3(f3 V, f3 H, float eta)   // pbr.cl:176-186
     return (-V) / eta + H * (ci / eta - ct);
 }
 
-__device__ inline f3 microfacet_brdf(f3 L, f3 V, f3 N, f3 albedo, float metallic, float roughness, float transmission)
+__device__ inline f3 microfacet_brdf(const NFrame& FN, f3 L, f3 V, f3 N, f3 albedo, float metallic, float roughness,
+                                     float transmission)
 {   // pbr.cl:268-287
     f3 H = normalize3(V + L);
     float NoV = cl_clamp(dot3(N, V), 0.0f, 1.0f);
@@ -117,58 +128,58 @@ __device__ inline f3 microfacet_brdf(f3 L, f3 V, f3 N, f3 albedo, float metallic
     float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
     f3 F = f_schlick(VoH, metallic, albedo);
     float D = d_ggx(NoH, roughness);
-    float G = g_pbrt(V, L, N, roughness);
+    float G = g_pbrt(FN, V, L, roughness);
     f3 spec = (F * (D * G)) / cl_max(4.0f * NoV * NoL, 0.001f);
     f3 notSpec = (one_minus(F) * (1.0f - metallic)) * (1.0f - transmission);
     f3 diff = notSpec * (albedo / RDX_PI);
     return (diff + spec) * NoL;
 }
 
-// local (theta, phi) direction rotated into the frame of `n`
-__device__ inline f3 frame_dir(f3 n, float theta, float phi)
+// local (theta, phi) direction rotated into a frame
+__device__ inline f3 frame_dir(const NFrame& F, float theta, float phi)
 {
     float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
-    float tbn[16];
-    normal_space(n, tbn);
-    return mat4_mul3(tbn, st * cp, st * sp, ct, 0.0f);
+    return mat4_mul3(F.tbn, st * cp, st * sp, ct, 0.0f);
 }
 
-// pbr.cl:289-385 sampleMicrofacetBRDF_transm
-__device__ inline f3 sample_brdf_transm(f3 V, f3 N, f3 base, float metallic, float roughness, float transmission,
-                                        float ior, f3 rnd, f3& nextFactor)
+// pbr.cl:289-385 sampleMicrofacetBRDF_transm.  The diffuse and the specular lobe share the frame of N,
+// the azimuth and the Fresnel term, so they run as one converged code path with selects; only the rare
+// transmission lobe (glass) branches off with the frame of the forward normal.
+__device__ inline f3 sample_brdf_transm(const NFrame& FN, f3 V, f3 N, f3 base, float metallic, float roughness,
+                                        float transmission, float ior, f3 rnd, f3& nextFactor)
 {
     const float ggxTheta = acosf(sqrtf((1.0f - rnd.y) / (1.0f + ((roughness * roughness) * (roughness * roughness) - 1.0f) * rnd.y)));
     const float phi = 2.0f * RDX_PI * rnd.x;
-    if (rnd.z < 0.5f) {
-        if ((2.0f * rnd.z) < transmission) {
-            f3 fn = N;
-            float eta = ior;
-            if (dot3(V, N) < 0.0f) { fn = -N; eta = 1.0f / ior; }
-            f3 H = frame_dir(fn, ggxTheta, phi);
-            f3 L = refract3(V, H, eta);
-            float NoV = cl_clamp(dot3(fn, V), 0.0f, 1.0f);
-            float NoH = cl_clamp(dot3(fn, H), 0.0f, 1.0f);
-            float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
-            f3 F = f_schlick(VoH, metallic, base);
-            float G = g_pbrt(V, -L, fn, roughness);
-            nextFactor = ((((base * one_minus(F)) * G) * VoH) / cl_max(NoH * NoV, 0.001f)) * 2.0f;
-            return L;
-        }
-        f3 L = frame_dir(N, acosf(sqrtf(rnd.y)), phi);
-        f3 H = normalize3(V + L);
+    const bool lower = rnd.z < 0.5f;
+    if (lower && (2.0f * rnd.z) < transmission) {
+        f3 fn = N;
+        float eta = ior;
+        NFrame FT;
+        if (dot3(V, N) < 0.0f) { fn = -N; eta = 1.0f / ior; make_frame(fn, FT); } else FT = FN;
+        f3 H = frame_dir(FT, ggxTheta, phi);
+        f3 L = refract3(V, H, eta);
+        float NoV = cl_clamp(dot3(fn, V), 0.0f, 1.0f);
+        float NoH = cl_clamp(dot3(fn, H), 0.0f, 1.0f);
         float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
         f3 F = f_schlick(VoH, metallic, base);
-        nextFactor = ((one_minus(F) * (1.0f - metallic)) * base) * 2.0f;
+        float G = g_pbrt(FT, V, -L, roughness);
+        nextFactor = ((((base * one_minus(F)) * G) * VoH) / cl_max(NoH * NoV, 0.001f)) * 2.0f;
         return L;
     }
-    f3 H = frame_dir(N, ggxTheta, phi);
-    f3 L = reflect3(V, H);
-    float NoV = cl_clamp(dot3(N, V), 0.0f, 1.0f);
-    float NoH = cl_clamp(dot3(N, H), 0.0f, 1.0f);
-    float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
-    float G = g_pbrt(V, L, N, roughness);
-    f3 F = f_schlick(VoH, metallic, base);
-    nextFactor = (((F * G) * VoH) / cl_max(NoH * NoV, 0.001f)) * 2.0f;
+    const bool diffuse = lower;
+    const f3 dirv = frame_dir(FN, diffuse ? acosf(sqrtf(rnd.y)) : ggxTheta, phi);
+    const f3 L = diffuse ? dirv : reflect3(V, dirv);
+    const f3 H = diffuse ? normalize3(V + L) : dirv;
+    const float VoH = cl_clamp(dot3(V, H), 0.0f, 1.0f);
+    const f3 F = f_schlick(VoH, metallic, base);
+    if (diffuse) {
+        nextFactor = ((one_minus(F) * (1.0f - metallic)) * base) * 2.0f;
+    } else {
+        const float NoV = cl_clamp(dot3(N, V), 0.0f, 1.0f);
+        const float NoH = cl_clamp(dot3(N, H), 0.0f, 1.0f);
+        const float G = g_pbrt(FN, V, L, roughness);
+        nextFactor = (((F * G) * VoH) / cl_max(NoH * NoV, 0.001f)) * 2.0f;
+    }
     return L;
 }
 
@@ -229,7 +240,9 @@ __device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s
     p.wantsShadowRay = true;
     p.shadowOrigin = hitPos;
     const float* lc = s.scene->lights[0].color;
-    f3 direct = mk3(0.0f, 0.0f, 0.0f) + microfacet_brdf(L, V, N, albedo, metallic, roughness, transmission) * mk3(lc[0], lc[1], lc[2]);
+    NFrame FN;
+    make_frame(N, FN);
+    f3 direct = mk3(0.0f, 0.0f, 0.0f) + microfacet_brdf(FN, L, V, N, albedo, metallic, roughness, transmission) * mk3(lc[0], lc[1], lc[2]);
     f3 ambient = albedo * 0.1f;
     p.color = direct + ambient;
     p.colorOccluded = mk3(0.0f, 0.0f, 0.0f) + ambient;
@@ -237,7 +250,7 @@ __device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s
     if (sampleNext) {
         f3 rnd = pcg3d(frameID, pixel, depth);
         f3 nf = mk3(0.0f, 0.0f, 0.0f);
-        f3 nd = sample_brdf_transm(V, N, albedo, metallic, roughness, transmission, ior, rnd, nf);
+        f3 nd = sample_brdf_transm(FN, V, N, albedo, metallic, roughness, transmission, ior, rnd, nf);
         if (dot3(nd, N) < 0) hitPos = offset_hit_position(h, -faceN);
         p.nextRayOrigin = hitPos;
         p.nextRayDirection = nd;
