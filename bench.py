@@ -97,10 +97,19 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-tracing core has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("RDX_DIST_BACKEND", "nccl")      # "gloo": rehearsal with ranks sharing a GPU
+    if local_rank >= ndev:
+        if backend == "nccl":
+            raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as tdist
-        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            tdist.init_process_group(backend)
     plt = rd.Platform.GetPlatform(local_rank)
 
     def run_workload(key, steps, warmup, want_roofline):

@@ -87,6 +87,15 @@ def gather_to_root(packed, world, dst=0, recv=None):
     bufs = None
     if rank == dst:
         bufs = recv if recv is not None else [torch.empty_like(packed) for _ in range(world)]
+    if packed.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal path (several ranks sharing one GPU, where RCCL refuses duplicate devices): stage
+        # through host memory; the production backend is nccl = RCCL
+        host = [torch.empty(packed.shape, dtype=packed.dtype) for _ in range(world)] if rank == dst else None
+        dist.gather(packed.cpu(), host, dst=dst)
+        if rank == dst:
+            for b, h in zip(bufs, host):
+                b.copy_(h)
+        return bufs
     dist.gather(packed, bufs, dst=dst)
     return bufs
 
