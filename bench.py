@@ -26,11 +26,32 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/
+    *_pmc_hbm.json, written by tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this
+    same command); None if there is none for this workload."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))):
+        try:
+            d = json.load(open(p))
+        except Exception:
+            continue
+        if d.get("workload", "sample1") != workload:
+            continue
+        k = d.get("kernels", {}).get(kernel)
+        if k:
+            best = (int(k["hbm_bytes_per_launch"]), os.path.basename(p))
+    return best
+
 WORKLOADS = {
     # BASELINE.json configs[1]: "sample1.cpp scene, 1920x1080, 4 spp, depth 8, 1xMI355X"
     "sample1": ("c1_cornell", "sample1 scene (procedural Cornell stand-in, 20.5k tris, 8 instances), 1920x1080, 4 spp, depth 8"),
     # BASELINE.json configs[2]: "Sponza via assimp (~260k tris) ..." -- no asset offline, procedural atrium
     "sponza": ("c2_atrium", "Sponza-class procedural atrium (262k tris, 25 instances), 1920x1080, 4 spp, depth 8"),
+    # BASELINE.json configs[4] geometry ("San-Miguel-scale ~10M tris"): BVH (446 MB) beyond L2 + Infinity Cache
+    "sanmiguel": ("c4_atrium_10m", "San-Miguel-scale procedural atrium (10.4M tris, 25 instances), 1920x1080, 4 spp, depth 8"),
 }
 
 
@@ -218,7 +239,8 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_extend",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[0],
+            "traffic_source": (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[1],
             "algorithmic_bytes_per_launch": int(bytes_extend_frame * steps / launches),
             "avg_launch_ms": round(acc["ms_extend"] / launches, 4),
             "launches": launches,

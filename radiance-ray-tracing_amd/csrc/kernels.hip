@@ -406,7 +406,7 @@ k_extend(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, float t
         traverse<1, true>(A, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
         ps.hitA[i] = make_float4(r.t, r.b1, r.b2, u2f(r.prim));
         ps.hitInst[i] = r.hit ? r.inst : RDX_MISS;
-        flush_visits(visit, 0, r);
+        if (visit) flush_visits(visit, 0, r);
     } else {
         Best b;
         traverse_wide<1>(A, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), tmin, tmax, s_stack + threadIdx.x, blockDim.x, b);
@@ -519,7 +519,7 @@ k_shadow(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__
         if (COUNT) {
             TraceResult r;
             traverse<2, true>(A, mk3(so.x, so.y, so.z), L, tmin, tmax, s_stack + threadIdx.x, blockDim.x, r);
-            flush_visits(visit, 1, r);
+            if (visit) flush_visits(visit, 1, r);
             anyHit = r.hit; hitInst = r.inst;
         } else {
             Best b;

@@ -13,12 +13,14 @@ the layout `RD::Scene::Load` produces:
     materialData                     : Material[], factor-only (all *TexIdx = -1: texture fetches are
                                        stubbed to 0 in the live shader, shader.cl:379-445)
 
-Everything is float32 arithmetic on seeds, so a scene is bit-identical wherever it is generated.
+Everything is derived from integer seeds; the oracle and the GPU path always consume the same arrays
+generated in the same process.
 
 Configs (BASELINE.json / SURVEY.md 8d):
     c0_two_boxes      two 12-triangle boxes, 256x256, 1 spp, depth 1        (plumbing)
     c1_cornell        Cornell-like box + 2 boxes + icosphere, 8 instances    (sample1 stand-in)
     c2_atrium         Sponza-class atrium, ~262k unique triangles, 25 instances
+    c4_atrium_10m     San-Miguel-scale: the same generator at 10.4 M unique triangles
 """
 import math
 
@@ -432,4 +434,12 @@ def c2_atrium(width=1920, height=1080, spp=4, depth=8, detail=1.0):
     return s
 
 
-CONFIGS = {"c0_two_boxes": c0_two_boxes, "c1_cornell": c1_cornell, "c2_atrium": c2_atrium}
+def c4_atrium_10m(width=1920, height=1080, spp=4, depth=8):
+    """BASELINE config 4 ("San-Miguel-scale"): the atrium generator at 6.3x tessellation = 10.4 M unique
+    triangles, 25 instances; the acceleration blob (446 MB) exceeds L2 and the 256 MB Infinity Cache."""
+    s = c2_atrium(width, height, spp, depth, detail=6.3)
+    s.name = "c4_atrium_10m"
+    return s
+
+
+CONFIGS = {"c0_two_boxes": c0_two_boxes, "c1_cornell": c1_cornell, "c2_atrium": c2_atrium, "c4_atrium_10m": c4_atrium_10m}

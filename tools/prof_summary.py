@@ -5,7 +5,7 @@ the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): 
 WRITE_SIZE are in KiB; FETCH_SIZE reads exactly 1/2 of a wide coalesced stream on gfx950, so the
 read side is reported both raw and doubled.
 
-usage: tools/prof_summary.py <prof_dir> <profiles_dir> <tag>
+usage: tools/prof_summary.py <prof_dir> <profiles_dir> <tag> [workload]
 """
 import collections
 import csv
@@ -30,6 +30,7 @@ def per_kernel(path, counter):
 
 def main():
     prof, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    workload = sys.argv[4] if len(sys.argv) > 4 else "sample1"
     os.makedirs(out, exist_ok=True)
     st = os.path.join(prof, "stats", "r1_kernel_stats.csv")
     if os.path.exists(st):
@@ -52,7 +53,7 @@ def main():
             "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024),
         }
     with open(os.path.join(out, "%s_pmc_hbm.json" % tag), "w") as fjs:
-        json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled "
+        json.dump({"workload": workload, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled "
                            "per the gfx950 calibration for wide coalesced reads (uncalibrated for other widths)",
                    "kernels": summ}, fjs, indent=1)
     print(json.dumps(summ, indent=1))
