@@ -120,7 +120,9 @@ int         rdx_set_profiling(int on);
 /* knobs: "chunk_paths" (paths in flight per chunk), "count_visits" (0/1: also count node /
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 2 = wave-
  * cooperative (default), 1 = per-lane wide nodes, 0 = reference order; all three give identical
- * results, the option exists for A/B measurements and cross-checks) */
+ * results, the option exists for A/B measurements and cross-checks), "overlap" (1 / 0 / -1 = auto:
+ * run the shadow stage of bounce d on a second HIP stream beside the extend stage of bounce d+1;
+ * auto enables it below 4 M paths per chunk, where single launches no longer fill the GPU) */
 int         rdx_set_option(const char* name, int64_t value);
 
 /* Test seams: run single stages on caller-supplied batches (device or host pointers are NOT

@@ -33,22 +33,28 @@ struct CameraArgs {                // slot 3 + per-frame constants hoisted out o
     float rotX[16], rotY[16], rotZ[16];   // EulerX/Y/ZToMat4x4(cam.wx/wy/wz), math.cl:185-252
 };
 
-// Wavefront path state.  Two sets of float4 streams that ping-pong:
-//   A (one entry per live path at the start of a bounce)
-//   B (one entry per path that hit something, compacted by the shade stage)
+// Wavefront path state: float4 streams, one entry per path.
+//   cur  (read by extend / shade of bounce d):  rayO, rayD, thr, col  + the hit record
+//   next (written by shade of bounce d, compacted to the paths that hit; they become `cur` of bounce
+//         d+1 -- the host swaps the pointers): nRayO, nRayD, nThr, and nCol, which the shadow stage of
+//         bounce d fills in
+//   shadow query of bounce d: shO, colLit, colSh
+// shade(d) -> { extend(d+1), shadow(d) } -> shade(d+1): extend(d+1) and shadow(d) touch disjoint streams
+// and may run concurrently on two HIP streams.
 struct PathStreams {
-    float4* rayO;      // A: origin.xyz, w = global pixel index (bits)
-    float4* rayD;      // A: direction.xyz, w = frameID (bits)
-    float4* thr;       // A: contribution.xyz, w = owned-pixel slot (bits)
-    float4* col;       // A: accumulated colour.xyz
-    float4* hitA;      // A: t, b1, b2, primitive slot->primID (bits)
-    uint32_t* hitInst; // A: instance slot or 0xffffffff (miss)
-    float4* shO;       // B: shadow-ray origin.xyz, w = pixel
-    float4* nextO;     // B: next origin.xyz, w = frameID
-    float4* nextD;     // B: next direction.xyz, w = slot
-    float4* thrN;      // B: contribution after this bounce
-    float4* colLit;    // B: colour if the light is visible
-    float4* colSh;     // B: colour if it is occluded
+    float4* rayO;      // origin.xyz, w = global pixel index (bits)
+    float4* rayD;      // direction.xyz, w = frameID (bits)
+    float4* thr;       // contribution.xyz, w = owned-pixel slot (bits)
+    float4* col;       // accumulated colour.xyz
+    float4* hitA;      // t, b1, b2, primID (bits)
+    uint32_t* hitInst; // instance slot or 0xffffffff (miss)
+    float4* nRayO;     // next bounce: origin | pixel
+    float4* nRayD;     // next bounce: direction | frameID
+    float4* nThr;      // next bounce: contribution after this bounce | slot
+    float4* nCol;      // next bounce: colour, chosen by the shadow stage
+    float4* shO;       // shadow-ray origin.xyz, w != 0: the closest-hit shader asked for a shadow query
+    float4* colLit;    // colour if the light is visible
+    float4* colSh;     // colour if it is occluded
     float4* sampleColor; // [samples_in_chunk][pixels] final per-sample radiance
 };
 

@@ -491,10 +491,10 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
     const f3 lit = Cc + T * p.color;               // color += contribution * payload.color (shader.cl:240)
     const f3 occ = Cc + T * p.colorOccluded;
     const f3 tn = T * p.nextFactor;                // contribution *= payload.nextFactor    (shader.cl:241)
-    ps.shO[j] = make_float4(p.shadowOrigin.x, p.shadowOrigin.y, p.shadowOrigin.z, ro.w);
-    ps.nextO[j] = make_float4(p.nextRayOrigin.x, p.nextRayOrigin.y, p.nextRayOrigin.z, rd.w);
-    ps.nextD[j] = make_float4(p.nextRayDirection.x, p.nextRayDirection.y, p.nextRayDirection.z, thr.w);
-    ps.thrN[j] = make_float4(tn.x, tn.y, tn.z, p.wantsShadowRay ? 1.0f : 0.0f);
+    ps.shO[j] = make_float4(p.shadowOrigin.x, p.shadowOrigin.y, p.shadowOrigin.z, p.wantsShadowRay ? 1.0f : 0.0f);
+    ps.nRayO[j] = make_float4(p.nextRayOrigin.x, p.nextRayOrigin.y, p.nextRayOrigin.z, ro.w);
+    ps.nRayD[j] = make_float4(p.nextRayDirection.x, p.nextRayDirection.y, p.nextRayDirection.z, rd.w);
+    ps.nThr[j] = make_float4(tn.x, tn.y, tn.z, thr.w);
     ps.colLit[j] = make_float4(lit.x, lit.y, lit.z, 0.0f);
     ps.colSh[j] = make_float4(occ.x, occ.y, occ.z, 0.0f);
 }
@@ -510,9 +510,8 @@ k_shadow(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *nPtr) return;
     const float4 so = ps.shO[i];
-    const float4 tn = ps.thrN[i];
     bool occluded = false;
-    if (tn.w != 0.0f) {
+    if (so.w != 0.0f) {
         const float* ld = sc.scene->lights[0].direction;
         const f3 L = normalize3(mk3(-ld[0], -ld[1], -ld[2]));     // shader.cl:471-476
         bool anyHit; uint32_t hitInst;
@@ -533,15 +532,11 @@ k_shadow(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__
         occluded = sp.hit;
     }
     const float4 c = occluded ? ps.colSh[i] : ps.colLit[i];
-    const float4 no = ps.nextO[i], nd = ps.nextD[i];
     if (lastBounce) {
-        store_sample(ps, nPixels, sampleBase, f2u(no.w), f2u(nd.w), mk3(c.x, c.y, c.z));
+        store_sample(ps, nPixels, sampleBase, f2u(ps.nRayD[i].w), f2u(ps.nThr[i].w), mk3(c.x, c.y, c.z));
         return;
     }
-    ps.rayO[i] = make_float4(no.x, no.y, no.z, so.w);
-    ps.rayD[i] = make_float4(nd.x, nd.y, nd.z, no.w);
-    ps.thr[i] = make_float4(tn.x, tn.y, tn.z, nd.w);
-    ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
+    ps.nCol[i] = make_float4(c.x, c.y, c.z, 0.0f);
 }
 
 // depth == 0 frames: every path ends with colour 0 without tracing
@@ -675,27 +670,21 @@ struct ShadowPolicy {
     {
         const float4 so = ps.shO[i];
         o = mk3(so.x, so.y, so.z); d = Ldir;
-        return ps.thrN[i].w != 0.0f;            // the closest-hit shader asked for a shadow query
+        return so.w != 0.0f;                    // the closest-hit shader asked for a shadow query
     }
     __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const
     {
         // hit -> closest-hit row 2 `shadow` sets payload.hit; miss -> row 4 `shadowMiss` clears it
-        const float4 tn = ps.thrN[i];
         bool occluded = false;
-        if (tn.w != 0.0f) {
+        if (ps.shO[i].w != 0.0f) {
             Payload sp; sp.hit = false;
             if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[b.inst].SBTOffset + 2, sp, hh, sv, Ldir, 0, 0, 0, false); }
             else callMiss(4, sp);
             occluded = sp.hit;
         }
         const float4 c = occluded ? ps.colSh[i] : ps.colLit[i];
-        const float4 no = ps.nextO[i], nd = ps.nextD[i];
-        if (lastBounce) { store_sample(ps, nPixels, sampleBase, f2u(no.w), f2u(nd.w), mk3(c.x, c.y, c.z)); return; }
-        const float4 so = ps.shO[i];
-        ps.rayO[i] = make_float4(no.x, no.y, no.z, so.w);
-        ps.rayD[i] = make_float4(nd.x, nd.y, nd.z, no.w);
-        ps.thr[i] = make_float4(tn.x, tn.y, tn.z, nd.w);
-        ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
+        if (lastBounce) { store_sample(ps, nPixels, sampleBase, f2u(ps.nRayD[i].w), f2u(ps.nThr[i].w), mk3(c.x, c.y, c.z)); return; }
+        ps.nCol[i] = make_float4(c.x, c.y, c.z, 0.0f);
     }
 };
 

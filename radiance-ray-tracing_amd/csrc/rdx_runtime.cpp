@@ -63,7 +63,9 @@ struct Context {
     bool initialized = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // shadow stage of bounce d runs here beside extend of bounce d+1
     hipEvent_t evA = nullptr, evB = nullptr;
+    hipEvent_t evShade[64] = {}, evShadow[64] = {};
     std::string err;
     std::vector<std::unique_ptr<rdx_buffer_s>> buffers;
     std::vector<std::unique_ptr<rdx_blas_s>> blases;
@@ -86,6 +88,7 @@ struct Context {
     int64_t chunkPaths = 16ll << 20;
     bool countVisits = false, profiling = false;
     int kernel = 2;                         // traversal kernel: 2 cooperative, 1 per-lane wide, 0 reference order
+    int overlap = -1;                       // extend(d+1) || shadow(d): 1 on, 0 off, -1 auto (on below 4 M paths per chunk)
     rdx_trace_stats stats{};
 };
 Context g;
@@ -319,8 +322,8 @@ AccelView view_of(const rdx_buffer_s* tb)
 int ensure_streams(size_t paths, size_t samplesTimesPixels)
 {
     if (paths > g.streamCap) {
-        float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.shO, &g.ps.nextO,
-                          &g.ps.nextD, &g.ps.thrN, &g.ps.colLit, &g.ps.colSh};
+        float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.nRayO, &g.ps.nRayD,
+                          &g.ps.nThr, &g.ps.nCol, &g.ps.shO, &g.ps.colLit, &g.ps.colSh};
         for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
         if (g.ps.hitInst) HIP_IGN(hipFree(g.ps.hitInst));
         g.ps.hitInst = nullptr;
@@ -406,8 +409,8 @@ struct StageTimer {
         if (used == pool.size()) { hipEvent_t e; HIP_IGN(hipEventCreate(&e)); pool.push_back(e); }
         return pool[used++];
     }
-    void begin(float* dst) { if (!g.profiling) return; Span s{get(), get(), dst}; HIP_IGN(hipEventRecord(s.a, g.stream)); spans.push_back(s); }
-    void end() { if (!g.profiling) return; HIP_IGN(hipEventRecord(spans.back().b, g.stream)); }
+    void begin(float* dst, hipStream_t st = nullptr) { if (!g.profiling) return; Span s{get(), get(), dst}; HIP_IGN(hipEventRecord(s.a, st ? st : g.stream)); spans.push_back(s); }
+    void end(hipStream_t st = nullptr) { if (!g.profiling) return; HIP_IGN(hipEventRecord(spans.back().b, st ? st : g.stream)); }
     void resolve()
     {
         for (auto& s : spans) { float ms = 0; HIP_IGN(hipEventElapsedTime(&ms, s.a, s.b)); *s.dst += ms; }
@@ -433,6 +436,11 @@ extern "C" int rdx_init(int device)
     HIP_OK(hipSetDevice(device));
     g.device = device;
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+    for (int i = 0; i < 64; ++i) {
+        HIP_OK(hipEventCreateWithFlags(&g.evShade[i], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&g.evShadow[i], hipEventDisableTiming));
+    }
     HIP_OK(hipEventCreate(&g.evA));
     HIP_OK(hipEventCreate(&g.evB));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dCounts), 256 * sizeof(uint32_t)));
@@ -449,8 +457,8 @@ extern "C" int rdx_shutdown(void)
     HIP_IGN(hipStreamSynchronize(g.stream));
     for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
     g.buffers.clear(); g.blases.clear(); g.shaders.clear();
-    float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.shO, &g.ps.nextO, &g.ps.nextD,
-                      &g.ps.thrN, &g.ps.colLit, &g.ps.colSh, &g.ps.sampleColor};
+    float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.nRayO, &g.ps.nRayD, &g.ps.nThr,
+                      &g.ps.nCol, &g.ps.shO, &g.ps.colLit, &g.ps.colSh, &g.ps.sampleColor};
     for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
     if (g.ps.hitInst) HIP_IGN(hipFree(g.ps.hitInst));
     if (g.ownedPixels) HIP_IGN(hipFree(g.ownedPixels));
@@ -459,6 +467,9 @@ extern "C" int rdx_shutdown(void)
     if (g.dVisit) HIP_IGN(hipFree(g.dVisit));
     if (g.hVisit) HIP_IGN(hipHostFree(g.hVisit));
     HIP_IGN(hipEventDestroy(g.evA)); HIP_IGN(hipEventDestroy(g.evB));
+    for (int i = 0; i < 64; ++i) { HIP_IGN(hipEventDestroy(g.evShade[i])); HIP_IGN(hipEventDestroy(g.evShadow[i])); }
+    HIP_IGN(hipStreamSynchronize(g.stream2));
+    HIP_IGN(hipStreamDestroy(g.stream2));
     HIP_IGN(hipStreamDestroy(g.stream));
     g = Context{};
     return 0;
@@ -721,6 +732,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!name) return fail("rdx_set_option: null name");
     if (!strcmp(name, "chunk_paths")) { if (value < 1) return fail("chunk_paths must be >= 1"); g.chunkPaths = value; return 0; }
     if (!strcmp(name, "count_visits")) { g.countVisits = value != 0; return 0; }
+    if (!strcmp(name, "overlap")) { if (value < -1 || value > 1) return fail("overlap must be -1 (auto), 0 or 1"); g.overlap = (int)value; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail("kernel must be 0, 1 or 2"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
 }
@@ -794,20 +806,36 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         if (maxDepth == 0) {
             launch_finalize_all(g.stream, g.ps, n0, P, sampleBase);
         }
+        // Per bounce: extend(d) -> shade(d) -> { shadow(d) , extend(d+1) } -> shade(d+1) ...
+        // shadow(d) only fills nCol (or the final sample colour) and reads streams nobody writes meanwhile, so
+        // with `overlap` it runs on the second stream beside extend(d+1); shade(d+1) waits for it.
+        const bool overlap = (g.overlap == 1 || (g.overlap == -1 && n0 <= (4u << 20))) && !visit;
+        PathStreams ps = g.ps;
         for (uint32_t d = 0; d < maxDepth; ++d) {
             g_timer.begin(&g.stats.ms_extend);
-            launch_extend(g.stream, av, g.ps, g.dCounts + d, n0, tmin, tmax, visit, g.dCounts + 64 + d);
+            launch_extend(g.stream, av, ps, g.dCounts + d, n0, tmin, tmax, visit, g.dCounts + 64 + d);
             g_timer.end();
             g.stats.launches_extend++;
+            if (overlap && d > 0) HIP_OK(hipStreamWaitEvent(g.stream, g.evShadow[d - 1], 0));   // shade(d) reads col written by shadow(d-1)
             g_timer.begin(&g.stats.ms_shade);
-            launch_shade(g.stream, av, sc, g.ps, g.dCounts + d, g.dCounts + d + 1, n0, d, maxDepth, P, sampleBase);
+            launch_shade(g.stream, av, sc, ps, g.dCounts + d, g.dCounts + d + 1, n0, d, maxDepth, P, sampleBase);
             g_timer.end();
-            g_timer.begin(&g.stats.ms_shadow);
-            launch_shadow(g.stream, av, sc, g.ps, g.dCounts + d + 1, n0, d + 1 == maxDepth, P, sampleBase, tmin, tmax, visit,
+            hipStream_t ss = g.stream;
+            if (overlap) {
+                HIP_OK(hipEventRecord(g.evShade[d], g.stream));
+                HIP_OK(hipStreamWaitEvent(g.stream2, g.evShade[d], 0));
+                ss = g.stream2;
+            }
+            g_timer.begin(&g.stats.ms_shadow, ss);
+            launch_shadow(ss, av, sc, ps, g.dCounts + d + 1, n0, d + 1 == maxDepth, P, sampleBase, tmin, tmax, visit,
                           g.dCounts + 128 + d);
-            g_timer.end();
+            g_timer.end(ss);
+            if (overlap) HIP_OK(hipEventRecord(g.evShadow[d], g.stream2));
             g.stats.launches_shadow++;
+            // the compacted survivors become the live paths of the next bounce
+            std::swap(ps.rayO, ps.nRayO); std::swap(ps.rayD, ps.nRayD); std::swap(ps.thr, ps.nThr); std::swap(ps.col, ps.nCol);
         }
+        if (overlap && maxDepth > 0) HIP_OK(hipStreamWaitEvent(g.stream, g.evShadow[maxDepth - 1], 0));
         g_timer.begin(&g.stats.ms_accumulate);
         launch_accumulate(g.stream, g.ps, owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
                           static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
