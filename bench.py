@@ -163,7 +163,7 @@ def main():
             frame()
         rd.SetProfiling(True)
         acc = dict(primary=0, bounce=0, shadow=0, hits=0, ms_extend=0.0, ms_shadow=0.0, ms_shade=0.0, ms_generate=0.0,
-                   ms_accumulate=0.0, ms_total=0.0, launches_extend=0)
+                   ms_accumulate=0.0, ms_total=0.0, ms_fused=0.0, launches_extend=0)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -171,7 +171,7 @@ def main():
             st = rd.GetTraceStats()
             acc["primary"] += st.rays_primary; acc["bounce"] += st.rays_bounce; acc["shadow"] += st.rays_shadow
             acc["hits"] += st.closest_hits
-            for k in ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulate", "ms_total"):
+            for k in ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulate", "ms_total", "ms_fused"):
                 acc[k] += getattr(st, k)
             acc["launches_extend"] += st.launches_extend
         sync()
@@ -210,11 +210,22 @@ def main():
     rays_extend_per_frame = (acc["primary"] + acc["bounce"]) / steps
     bytes_extend_frame = algorithmic_bytes(visits["visit_top_nodes"][0], visits["visit_instances"][0],
                                            visits["visit_bot_nodes"][0], visits["visit_triangles"][0], rays_extend_per_frame)
-    launches = max(1, acc["launches_extend"])
-    ext_s = acc["ms_extend"] * 1e-3
-    achieved = bytes_extend_frame * steps / ext_s / 1e9 if ext_s > 0 else 0.0
     bytes_shadow_frame = algorithmic_bytes(visits["visit_top_nodes"][1], visits["visit_instances"][1],
                                            visits["visit_bot_nodes"][1], visits["visit_triangles"][1], acc["shadow"] / steps)
+    fused = acc["ms_fused"] > 0.0
+    if fused:
+        # small chunks: shadow(d) and extend(d+1) share one launch, so the dominant "kernel" is the traversal as a
+        # whole: all closest-hit + any-hit bytes over the time of every traversal launch of the timed region
+        kernel_name = "k_fused_coop + k_extend_coop + k_shadow_coop (all traversal launches)"
+        trav_s = (acc["ms_extend"] + acc["ms_shadow"] + acc["ms_fused"]) * 1e-3
+        roof_bytes = bytes_extend_frame + bytes_shadow_frame
+        launches = max(1, steps * (args.depth + 1))
+    else:
+        kernel_name = "k_extend"
+        trav_s = acc["ms_extend"] * 1e-3
+        roof_bytes = bytes_extend_frame
+        launches = max(1, acc["launches_extend"])
+    achieved = roof_bytes * steps / trav_s / 1e9 if trav_s > 0 else 0.0
     pixels = args.width * args.height if world == 1 else None
     frame_bytes = bytes_extend_frame + bytes_shadow_frame + 184 * acc["hits"] / steps + (20 * pixels if pixels else 0)
     out = {
@@ -237,12 +248,12 @@ def main():
                            "note": "rank 0 share" if world > 1 else "whole frame"},
         "Mrays_per_s_primary_plus_bounce": round(rays_pb / dt / 1e6, 3),
         "roofline": {
-            "bound": "hbm", "kernel": "k_extend",
+            "bound": "hbm", "kernel": kernel_name,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[0],
-            "traffic_source": (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[1],
-            "algorithmic_bytes_per_launch": int(bytes_extend_frame * steps / launches),
-            "avg_launch_ms": round(acc["ms_extend"] / launches, 4),
+            "traffic": None if fused else (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[0],
+            "traffic_source": None if fused else (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[1],
+            "algorithmic_bytes_per_launch": int(roof_bytes * steps / launches),
+            "avg_launch_ms": round(1e3 * trav_s / launches, 4),
             "launches": launches,
             "note": "achieved = reference-walk bytes (16/ray + 48/node + 96/instance visit + 64/triangle) of the k_extend "
                     "launches in the timed region / their HIP-event time; traffic (PMC) see profiles/",
@@ -250,7 +261,7 @@ def main():
         "roofline_frame": {"algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2) if world == 1 else None,
                            "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if world == 1 else None,
                            "bytes_per_frame": int(frame_bytes)},
-        "stage_ms_per_frame": {k[3:]: round(acc[k] / steps, 4) for k in ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_accumulate", "ms_total")},
+        "stage_ms_per_frame": {k[3:]: round(acc[k] / steps, 4) for k in ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_fused", "ms_accumulate", "ms_total")},
         "device": rd.Platform.device_name(),
     }
     if also:

@@ -111,7 +111,7 @@ typedef struct rdx_trace_stats {
      * "count_visits" is 1: index 0 = radiance rays, 1 = shadow rays (SURVEY.md 8d byte model) */
     uint64_t visit_top_nodes[2], visit_instances[2], visit_bot_nodes[2], visit_triangles[2];
     float    ms_total;                                 /* HIP-event time of the whole call */
-    float    ms_generate, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_sort;
+    float    ms_generate, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_fused;  /* ms_fused: shadow(d)+extend(d+1) launches */
     uint32_t launches_extend, launches_shadow;
 } rdx_trace_stats;
 int         rdx_get_trace_stats(rdx_trace_stats* out);
@@ -120,9 +120,10 @@ int         rdx_set_profiling(int on);
 /* knobs: "chunk_paths" (paths in flight per chunk), "count_visits" (0/1: also count node /
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 2 = wave-
  * cooperative (default), 1 = per-lane wide nodes, 0 = reference order; all three give identical
- * results, the option exists for A/B measurements and cross-checks), "overlap" (1 / 0 / -1 = auto:
- * run the shadow stage of bounce d on a second HIP stream beside the extend stage of bounce d+1;
- * auto enables it below 4 M paths per chunk, where single launches no longer fill the GPU) */
+ * results, the option exists for A/B measurements and cross-checks), "fuse" (1 / 0 / -1 = auto: trace
+ * the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch; auto enables
+ * it below 4 M paths per chunk, where the fixed ramp + tail cost of a launch dominates), "overlap" and
+ * "groups" (experimental: second-stream overlap / concurrent sample groups; off by default) */
 int         rdx_set_option(const char* name, int64_t value);
 
 /* Test seams: run single stages on caller-supplied batches (device or host pointers are NOT

@@ -68,6 +68,9 @@ void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
 void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
                    uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,
                    unsigned long long* visit, uint32_t* counter);
+// shadow(d) of `psShadow` and extend(d+1) of `psExtend` (its streams already swapped) in one cooperative launch
+void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& psShadow, const PathStreams& psExtend,
+                  const uint32_t* mPtr, uint32_t mMax, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, uint32_t* counter);
 void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* ownedPixels, uint32_t nPixels,
                        uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples, bool tonemap, uint32_t debug,
                        float* imageScratch, uint8_t* image);

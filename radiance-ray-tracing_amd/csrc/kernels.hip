@@ -651,10 +651,11 @@ __device__ __forceinline__ void write_hit_record(const AccelView& A, const Trace
 // ---------------------------------------------------------------------------------------------
 struct ExtendPolicy {
     AccelView A; PathStreams ps;
-    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) const
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
     {
         const float4 ro = ps.rayO[i], rd = ps.rayD[i];
         o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
+        anyHit = false;
         return true;
     }
     __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const
@@ -666,10 +667,11 @@ struct ExtendPolicy {
 
 struct ShadowPolicy {
     AccelView A; PathStreams ps; f3 Ldir; uint32_t lastBounce, nPixels, sampleBase;
-    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d) const
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
     {
         const float4 so = ps.shO[i];
         o = mk3(so.x, so.y, so.z); d = Ldir;
+        anyHit = true;
         return so.w != 0.0f;                    // the closest-hit shader asked for a shadow query
     }
     __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const
@@ -704,11 +706,40 @@ k_shadow_coop(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restr
     traverse_coop<2>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
 }
 
+// shadow(d) and extend(d+1) in ONE launch: both have counts[d+1] rays and touch disjoint streams
+// (ShadowPolicy: shO/colLit/colSh -> nCol; ExtendPolicy on the next bounce's streams: rayO/rayD -> hit).
+// Ray index i < m is shadow ray i of bounce d, i >= m is extend ray i - m of bounce d+1.  One launch
+// instead of two halves the fixed ramp + tail cost per bounce, which is what limits small frames
+// (multi-GPU shards): see tools/trav_scale.py.
+struct FusedPolicy {
+    ShadowPolicy sh; ExtendPolicy ex; uint32_t m;
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
+    {
+        return i < m ? sh.load(i, o, d, anyHit) : ex.load(i - m, o, d, anyHit);
+    }
+    __device__ __forceinline__ void store(uint32_t i, const Best& b, f3 o, f3 d) const
+    {
+        if (i < m) sh.store(i, b, o, d); else ex.store(i - m, b, o, d);
+    }
+};
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
+             uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
+{
+    const float* ld = sc.scene->lights[0].direction;
+    const uint32_t m = *mPtr;
+    FusedPolicy pol{ShadowPolicy{A, psShadow, normalize3(mk3(-ld[0], -ld[1], -ld[2])), 0u, nPixels, sampleBase},
+                    ExtendPolicy{A, psExtend}, m};
+    traverse_coop<3>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
+}
+
 struct BatchPolicy {
     AccelView A; const float* o; const float* d; rdx_hit* out;
-    __device__ __forceinline__ bool load(uint32_t i, f3& ro, f3& rd) const
+    __device__ __forceinline__ bool load(uint32_t i, f3& ro, f3& rd, bool& anyHit) const
     {
         ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        anyHit = false;
         return true;
     }
     __device__ __forceinline__ void store(uint32_t i, const Best& b, f3 ro, f3 rd) const
@@ -884,6 +915,15 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
     else
         hipLaunchKernelGGL(k_shadow<false>, dim3(blocks_for(nMax, th)), dim3(th), lds, st, av, sc, ps, nPtr,
                            lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax, visit);
+}
+
+void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& psShadow, const PathStreams& psExtend,
+                  const uint32_t* mPtr, uint32_t mMax, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, uint32_t* counter)
+{
+    if (!mMax) return;
+    size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
+    hipLaunchKernelGGL(k_fused_coop, dim3(coop_blocks(2u * mMax, th, lds)), dim3(th), lds, st, av, sc, psShadow, psExtend, mPtr,
+                       counter, nPixels, sampleBase, tmin, tmax);
 }
 
 void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* owned, uint32_t nPixels, uint32_t sampleBegin,

@@ -63,9 +63,7 @@ struct Context {
     bool initialized = false;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // shadow stage of bounce d runs here beside extend of bounce d+1
-    hipEvent_t evA = nullptr, evB = nullptr;
-    hipEvent_t evShade[64] = {}, evShadow[64] = {};
+    hipEvent_t evA = nullptr, evB = nullptr, evChunk = nullptr;
     std::string err;
     std::vector<std::unique_ptr<rdx_buffer_s>> buffers;
     std::vector<std::unique_ptr<rdx_blas_s>> blases;
@@ -77,18 +75,31 @@ struct Context {
     uint32_t rank = 0, world = 1, tileW = 64, tileH = 64;
     uint32_t* ownedPixels = nullptr; uint32_t ownedCount = 0, ownedW = 0, ownedH = 0, ownedRank = 0, ownedWorld = 0,
               ownedTileW = 0, ownedTileH = 0;
-    // path streams
-    size_t streamCap = 0, sampleCap = 0;
-    PathStreams ps{};
-    uint32_t* dCounts = nullptr;            // [0] = paths generated, [d+1] = hits of bounce d
-    uint32_t* hCounts = nullptr;            // pinned
+    // path streams: up to MAX_GROUPS independent sets of paths in flight (sample groups of one chunk);
+    // each has its own streams (s0: generate/extend/shade, s1: shadow beside the next extend), live
+    // counts and events, so launches of different groups overlap and cover each other's tails
+    struct Group {
+        PathStreams ps{};
+        size_t cap = 0;
+        uint32_t* dCounts = nullptr;        // [0] = paths generated, [d+1] = hits of bounce d, [64+d] / [128+d] ray counters
+        uint32_t* hCounts = nullptr;        // pinned
+        hipStream_t s0 = nullptr, s1 = nullptr;
+        hipEvent_t evShade[64] = {}, evShadow[64] = {}, evDone = nullptr;
+    };
+    static constexpr int MAX_GROUPS = 4;
+    Group groups[MAX_GROUPS];
+    size_t sampleCap = 0;
+    float4* sampleColor = nullptr;
+    uint32_t* dCounts = nullptr;            // = groups[0].dCounts (test seams)
+    int groupsOpt = 1;                      // sample groups in flight (experimental): 1..4
+    int fuse = -1;                          // shadow(d) + extend(d+1) in one launch: 1 on, 0 off, -1 auto (small chunks)
     unsigned long long* dVisit = nullptr;   // 8 words
     unsigned long long* hVisit = nullptr;   // pinned
     // options
     int64_t chunkPaths = 16ll << 20;
     bool countVisits = false, profiling = false;
     int kernel = 2;                         // traversal kernel: 2 cooperative, 1 per-lane wide, 0 reference order
-    int overlap = -1;                       // extend(d+1) || shadow(d): 1 on, 0 off, -1 auto (on below 4 M paths per chunk)
+    int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
     rdx_trace_stats stats{};
 };
 Context g;
@@ -319,25 +330,28 @@ AccelView view_of(const rdx_buffer_s* tb)
 }
 
 // ---- path streams --------------------------------------------------------------------------------
-int ensure_streams(size_t paths, size_t samplesTimesPixels)
+int ensure_group(Context::Group& G, size_t paths)
 {
-    if (paths > g.streamCap) {
-        float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.nRayO, &g.ps.nRayD,
-                          &g.ps.nThr, &g.ps.nCol, &g.ps.shO, &g.ps.colLit, &g.ps.colSh};
-        for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
-        if (g.ps.hitInst) HIP_IGN(hipFree(g.ps.hitInst));
-        g.ps.hitInst = nullptr;
-        g.streamCap = 0;
-        for (auto a : arr) HIP_OK(hipMalloc(reinterpret_cast<void**>(a), paths * sizeof(float4)));
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.ps.hitInst), paths * sizeof(uint32_t)));
-        g.streamCap = paths;
-    }
-    if (samplesTimesPixels > g.sampleCap) {
-        if (g.ps.sampleColor) HIP_IGN(hipFree(g.ps.sampleColor));
-        g.ps.sampleColor = nullptr; g.sampleCap = 0;
-        HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.ps.sampleColor), samplesTimesPixels * sizeof(float4)));
-        g.sampleCap = samplesTimesPixels;
-    }
+    if (paths <= G.cap) return 0;
+    float4** arr[] = {&G.ps.rayO, &G.ps.rayD, &G.ps.thr, &G.ps.col, &G.ps.hitA, &G.ps.nRayO, &G.ps.nRayD,
+                      &G.ps.nThr, &G.ps.nCol, &G.ps.shO, &G.ps.colLit, &G.ps.colSh};
+    for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
+    if (G.ps.hitInst) HIP_IGN(hipFree(G.ps.hitInst));
+    G.ps.hitInst = nullptr;
+    G.cap = 0;
+    for (auto a : arr) HIP_OK(hipMalloc(reinterpret_cast<void**>(a), paths * sizeof(float4)));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.ps.hitInst), paths * sizeof(uint32_t)));
+    G.cap = paths;
+    return 0;
+}
+
+int ensure_samples(size_t samplesTimesPixels)
+{
+    if (samplesTimesPixels <= g.sampleCap) return 0;
+    if (g.sampleColor) HIP_IGN(hipFree(g.sampleColor));
+    g.sampleColor = nullptr; g.sampleCap = 0;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.sampleColor), samplesTimesPixels * sizeof(float4)));
+    g.sampleCap = samplesTimesPixels;
     return 0;
 }
 
@@ -436,15 +450,23 @@ extern "C" int rdx_init(int device)
     HIP_OK(hipSetDevice(device));
     g.device = device;
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
-    for (int i = 0; i < 64; ++i) {
-        HIP_OK(hipEventCreateWithFlags(&g.evShade[i], hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&g.evShadow[i], hipEventDisableTiming));
-    }
     HIP_OK(hipEventCreate(&g.evA));
     HIP_OK(hipEventCreate(&g.evB));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dCounts), 256 * sizeof(uint32_t)));
-    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hCounts), 256 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_OK(hipEventCreateWithFlags(&g.evChunk, hipEventDisableTiming));
+    for (int k = 0; k < Context::MAX_GROUPS; ++k) {
+        Context::Group& G = g.groups[k];
+        if (k == 0) G.s0 = g.stream; else HIP_OK(hipStreamCreateWithFlags(&G.s0, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&G.s1, hipStreamNonBlocking));
+        for (int i = 0; i < 64; ++i) {
+            HIP_OK(hipEventCreateWithFlags(&G.evShade[i], hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&G.evShadow[i], hipEventDisableTiming));
+        }
+        HIP_OK(hipEventCreateWithFlags(&G.evDone, hipEventDisableTiming));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.dCounts), 256 * sizeof(uint32_t)));
+        HIP_OK(hipMemset(G.dCounts, 0, 256 * sizeof(uint32_t)));
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&G.hCounts), 256 * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    g.dCounts = g.groups[0].dCounts;
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dVisit), 8 * sizeof(unsigned long long)));
     HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hVisit), 8 * sizeof(unsigned long long), hipHostMallocDefault));
     g.initialized = true;
@@ -457,19 +479,24 @@ extern "C" int rdx_shutdown(void)
     HIP_IGN(hipStreamSynchronize(g.stream));
     for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
     g.buffers.clear(); g.blases.clear(); g.shaders.clear();
-    float4** arr[] = {&g.ps.rayO, &g.ps.rayD, &g.ps.thr, &g.ps.col, &g.ps.hitA, &g.ps.nRayO, &g.ps.nRayD, &g.ps.nThr,
-                      &g.ps.nCol, &g.ps.shO, &g.ps.colLit, &g.ps.colSh, &g.ps.sampleColor};
-    for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
-    if (g.ps.hitInst) HIP_IGN(hipFree(g.ps.hitInst));
+    for (int k = 0; k < Context::MAX_GROUPS; ++k) {
+        Context::Group& G = g.groups[k];
+        float4** arr[] = {&G.ps.rayO, &G.ps.rayD, &G.ps.thr, &G.ps.col, &G.ps.hitA, &G.ps.nRayO, &G.ps.nRayD, &G.ps.nThr,
+                          &G.ps.nCol, &G.ps.shO, &G.ps.colLit, &G.ps.colSh};
+        for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; }
+        if (G.ps.hitInst) HIP_IGN(hipFree(G.ps.hitInst));
+        if (G.dCounts) HIP_IGN(hipFree(G.dCounts));
+        if (G.hCounts) HIP_IGN(hipHostFree(G.hCounts));
+        for (int i = 0; i < 64; ++i) { HIP_IGN(hipEventDestroy(G.evShade[i])); HIP_IGN(hipEventDestroy(G.evShadow[i])); }
+        HIP_IGN(hipEventDestroy(G.evDone));
+        HIP_IGN(hipStreamSynchronize(G.s1)); HIP_IGN(hipStreamDestroy(G.s1));
+        if (k > 0) { HIP_IGN(hipStreamSynchronize(G.s0)); HIP_IGN(hipStreamDestroy(G.s0)); }
+    }
+    if (g.sampleColor) HIP_IGN(hipFree(g.sampleColor));
     if (g.ownedPixels) HIP_IGN(hipFree(g.ownedPixels));
-    if (g.dCounts) HIP_IGN(hipFree(g.dCounts));
-    if (g.hCounts) HIP_IGN(hipHostFree(g.hCounts));
     if (g.dVisit) HIP_IGN(hipFree(g.dVisit));
     if (g.hVisit) HIP_IGN(hipHostFree(g.hVisit));
-    HIP_IGN(hipEventDestroy(g.evA)); HIP_IGN(hipEventDestroy(g.evB));
-    for (int i = 0; i < 64; ++i) { HIP_IGN(hipEventDestroy(g.evShade[i])); HIP_IGN(hipEventDestroy(g.evShadow[i])); }
-    HIP_IGN(hipStreamSynchronize(g.stream2));
-    HIP_IGN(hipStreamDestroy(g.stream2));
+    HIP_IGN(hipEventDestroy(g.evA)); HIP_IGN(hipEventDestroy(g.evB)); HIP_IGN(hipEventDestroy(g.evChunk));
     HIP_IGN(hipStreamDestroy(g.stream));
     g = Context{};
     return 0;
@@ -732,7 +759,9 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!name) return fail("rdx_set_option: null name");
     if (!strcmp(name, "chunk_paths")) { if (value < 1) return fail("chunk_paths must be >= 1"); g.chunkPaths = value; return 0; }
     if (!strcmp(name, "count_visits")) { g.countVisits = value != 0; return 0; }
-    if (!strcmp(name, "overlap")) { if (value < -1 || value > 1) return fail("overlap must be -1 (auto), 0 or 1"); g.overlap = (int)value; return 0; }
+    if (!strcmp(name, "groups")) { if (value < 1 || value > Context::MAX_GROUPS) return fail("groups must be 1..4"); g.groupsOpt = (int)value; return 0; }
+    if (!strcmp(name, "overlap")) { if (value < 0 || value > 1) return fail("overlap must be 0 or 1"); g.overlap = (int)value; return 0; }
+    if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail("kernel must be 0, 1 or 2"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
 }
@@ -788,67 +817,114 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
     const uint32_t batch = rt.batchSize;
     uint32_t samplesPerChunk = batch;
     if (P && (uint64_t)batch * P > (uint64_t)g.chunkPaths) samplesPerChunk = (uint32_t)std::max<int64_t>(1, g.chunkPaths / P);
-    if (P && batch) { if (ensure_streams((size_t)samplesPerChunk * P, (size_t)samplesPerChunk * P)) return -1; }
+    if (P && batch) { if (ensure_samples((size_t)samplesPerChunk * P)) return -1; }
 
     const float tmin = 0.001f, tmax = 1000.0f;      // shader.cl:235-236, 500
     for (uint32_t s0 = 0; s0 < batch && P; s0 += samplesPerChunk) {
         const uint32_t sc_n = std::min(samplesPerChunk, batch - s0);
-        const uint32_t n0 = sc_n * P;
         const uint32_t sampleBase = rt.totalSamples + s0;
-        // counts[0] = n0, counts[1..] = 0
-        std::memset(g.hCounts, 0, 256 * sizeof(uint32_t));
-        g.hCounts[0] = n0;
-        HIP_OK(hipMemcpyAsync(g.dCounts, g.hCounts, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+        const uint64_t chunkPaths = (uint64_t)sc_n * P;
+        // Small chunks (multi-GPU shards, low resolutions) no longer fill the GPU with one launch and every
+        // traversal launch ends in a tail of a few long rays: split the chunk's samples into up to 4 groups
+        // with their own streams, so the launches of one group run inside the tails of the others.
+        const bool small = chunkPaths <= (4ull << 20);
+        int nGroups = (int)std::min<uint32_t>((uint32_t)(visit ? 1 : g.groupsOpt), sc_n);
+        // Small chunks (multi-GPU shards, low resolutions): a traversal launch costs ~0.2 ms of ramp + tail
+        // whatever its size (tools/trav_scale.py), so shadow(d) and extend(d+1) -- same ray count, disjoint
+        // streams -- go into ONE cooperative launch: 9 traversal launches per depth-8 frame instead of 16.
+        const bool fuse = (g.fuse == 1 || (g.fuse == -1 && small)) && !visit && av.kernel == 2;
+        const bool overlap = g.overlap == 1 && !fuse && !visit;
+        HIP_OK(hipEventRecord(g.evChunk, g.stream));          // everything before this chunk (previous accumulate) is done first
 
-        g_timer.begin(&g.stats.ms_generate);
-        launch_generate(g.stream, C, g.ps, owned, P, s0, sc_n, rt.totalSamples);
-        g_timer.end();
-        if (maxDepth == 0) {
-            launch_finalize_all(g.stream, g.ps, n0, P, sampleBase);
-        }
-        // Per bounce: extend(d) -> shade(d) -> { shadow(d) , extend(d+1) } -> shade(d+1) ...
-        // shadow(d) only fills nCol (or the final sample colour) and reads streams nobody writes meanwhile, so
-        // with `overlap` it runs on the second stream beside extend(d+1); shade(d+1) waits for it.
-        const bool overlap = (g.overlap == 1 || (g.overlap == -1 && n0 <= (4u << 20))) && !visit;
-        PathStreams ps = g.ps;
-        for (uint32_t d = 0; d < maxDepth; ++d) {
-            g_timer.begin(&g.stats.ms_extend);
-            launch_extend(g.stream, av, ps, g.dCounts + d, n0, tmin, tmax, visit, g.dCounts + 64 + d);
-            g_timer.end();
-            g.stats.launches_extend++;
-            if (overlap && d > 0) HIP_OK(hipStreamWaitEvent(g.stream, g.evShadow[d - 1], 0));   // shade(d) reads col written by shadow(d-1)
-            g_timer.begin(&g.stats.ms_shade);
-            launch_shade(g.stream, av, sc, ps, g.dCounts + d, g.dCounts + d + 1, n0, d, maxDepth, P, sampleBase);
-            g_timer.end();
-            hipStream_t ss = g.stream;
-            if (overlap) {
-                HIP_OK(hipEventRecord(g.evShade[d], g.stream));
-                HIP_OK(hipStreamWaitEvent(g.stream2, g.evShade[d], 0));
-                ss = g.stream2;
+        uint32_t gBegin[Context::MAX_GROUPS + 1];
+        for (int k = 0; k <= nGroups; ++k) gBegin[k] = (uint32_t)((uint64_t)sc_n * k / nGroups);
+        PathStreams gps[Context::MAX_GROUPS];
+        for (int k = 0; k < nGroups; ++k) {
+            Context::Group& G = g.groups[k];
+            const uint32_t ns = gBegin[k + 1] - gBegin[k], n0 = ns * P;
+            if (ensure_group(G, n0)) return -1;
+            G.ps.sampleColor = g.sampleColor;
+            gps[k] = G.ps;
+            if (k > 0) HIP_OK(hipStreamWaitEvent(G.s0, g.evChunk, 0));
+            std::memset(G.hCounts, 0, 256 * sizeof(uint32_t));
+            G.hCounts[0] = n0;
+            HIP_OK(hipMemcpyAsync(G.dCounts, G.hCounts, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, G.s0));
+            g_timer.begin(&g.stats.ms_generate, G.s0);
+            launch_generate(G.s0, C, gps[k], owned, P, s0 + gBegin[k], ns, rt.totalSamples);
+            g_timer.end(G.s0);
+            if (maxDepth == 0) launch_finalize_all(G.s0, gps[k], n0, P, sampleBase);
+            if (maxDepth > 0) {
+                g_timer.begin(&g.stats.ms_extend, G.s0);
+                launch_extend(G.s0, av, gps[k], G.dCounts, n0, tmin, tmax, visit, G.dCounts + 64);
+                g_timer.end(G.s0);
+                g.stats.launches_extend++;
             }
-            g_timer.begin(&g.stats.ms_shadow, ss);
-            launch_shadow(ss, av, sc, ps, g.dCounts + d + 1, n0, d + 1 == maxDepth, P, sampleBase, tmin, tmax, visit,
-                          g.dCounts + 128 + d);
-            g_timer.end(ss);
-            if (overlap) HIP_OK(hipEventRecord(g.evShadow[d], g.stream2));
-            g.stats.launches_shadow++;
-            // the compacted survivors become the live paths of the next bounce
-            std::swap(ps.rayO, ps.nRayO); std::swap(ps.rayD, ps.nRayD); std::swap(ps.thr, ps.nThr); std::swap(ps.col, ps.nCol);
         }
-        if (overlap && maxDepth > 0) HIP_OK(hipStreamWaitEvent(g.stream, g.evShadow[maxDepth - 1], 0));
+        // Per bounce and group:  shade(d) -> { shadow(d), extend(d+1) } -> shade(d+1) ...
+        // shadow(d) only fills nCol (or the final sample colour) and reads streams nobody writes meanwhile;
+        // extend(d+1) reads the next-bounce rays shade(d) wrote.  The two are traced by one fused launch,
+        // by two launches back to back, or (overlap) on two streams.
+        for (uint32_t d = 0; d < maxDepth; ++d) {
+            for (int k = 0; k < nGroups; ++k) {
+                Context::Group& G = g.groups[k];
+                PathStreams& ps = gps[k];
+                const uint32_t n0 = (gBegin[k + 1] - gBegin[k]) * P;
+                const bool last = d + 1 == maxDepth;
+                if (overlap && d > 0) HIP_OK(hipStreamWaitEvent(G.s0, G.evShadow[d - 1], 0));   // shade(d) reads col written by shadow(d-1)
+                g_timer.begin(&g.stats.ms_shade, G.s0);
+                launch_shade(G.s0, av, sc, ps, G.dCounts + d, G.dCounts + d + 1, n0, d, maxDepth, P, sampleBase);
+                g_timer.end(G.s0);
+                const PathStreams psShadow = ps;
+                // the compacted survivors become the live paths of the next bounce
+                std::swap(ps.rayO, ps.nRayO); std::swap(ps.rayD, ps.nRayD); std::swap(ps.thr, ps.nThr); std::swap(ps.col, ps.nCol);
+                if (fuse && !last) {
+                    g_timer.begin(&g.stats.ms_fused, G.s0);
+                    launch_fused(G.s0, av, sc, psShadow, ps, G.dCounts + d + 1, n0, P, sampleBase, tmin, tmax, G.dCounts + 128 + d);
+                    g_timer.end(G.s0);
+                    g.stats.launches_shadow++; g.stats.launches_extend++;
+                    continue;
+                }
+                hipStream_t ss = G.s0;
+                if (overlap) {
+                    HIP_OK(hipEventRecord(G.evShade[d], G.s0));
+                    HIP_OK(hipStreamWaitEvent(G.s1, G.evShade[d], 0));
+                    ss = G.s1;
+                }
+                g_timer.begin(&g.stats.ms_shadow, ss);
+                launch_shadow(ss, av, sc, psShadow, G.dCounts + d + 1, n0, last, P, sampleBase, tmin, tmax, visit, G.dCounts + 128 + d);
+                g_timer.end(ss);
+                if (overlap) HIP_OK(hipEventRecord(G.evShadow[d], G.s1));
+                g.stats.launches_shadow++;
+                if (!last) {
+                    g_timer.begin(&g.stats.ms_extend, G.s0);
+                    launch_extend(G.s0, av, ps, G.dCounts + d + 1, n0, tmin, tmax, visit, G.dCounts + 64 + d + 1);
+                    g_timer.end(G.s0);
+                    g.stats.launches_extend++;
+                }
+            }
+        }
+        for (int k = 0; k < nGroups; ++k) {
+            Context::Group& G = g.groups[k];
+            if (overlap && maxDepth > 0) HIP_OK(hipStreamWaitEvent(G.s0, G.evShadow[maxDepth - 1], 0));
+            HIP_OK(hipMemcpyAsync(G.hCounts, G.dCounts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, G.s0));
+            if (k > 0) { HIP_OK(hipEventRecord(G.evDone, G.s0)); HIP_OK(hipStreamWaitEvent(g.stream, G.evDone, 0)); }
+        }
         g_timer.begin(&g.stats.ms_accumulate);
-        launch_accumulate(g.stream, g.ps, owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
+        launch_accumulate(g.stream, gps[0], owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
                           static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
         g_timer.end();
-        HIP_OK(hipMemcpyAsync(g.hCounts, g.dCounts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
         HIP_OK(hipStreamSynchronize(g.stream));
-        if (maxDepth) g.stats.rays_primary += g.hCounts[0];
-        for (uint32_t d = 1; d < maxDepth; ++d) g.stats.rays_bounce += g.hCounts[d];
-        for (uint32_t d = 0; d < maxDepth; ++d) { g.stats.rays_shadow += g.hCounts[d + 1]; g.stats.closest_hits += g.hCounts[d + 1]; }
+        for (int k = 0; k < nGroups; ++k) {
+            const uint32_t* hc = g.groups[k].hCounts;
+            if (maxDepth) g.stats.rays_primary += hc[0];
+            for (uint32_t d = 1; d < maxDepth; ++d) g.stats.rays_bounce += hc[d];
+            for (uint32_t d = 0; d < maxDepth; ++d) { g.stats.rays_shadow += hc[d + 1]; g.stats.closest_hits += hc[d + 1]; }
+        }
     }
     if (batch == 0 && P) {
         // no samples: only the tonemap of the existing accumulator runs (shader.cl:283-304)
-        launch_accumulate(g.stream, g.ps, owned, P, 0, 0, rt.totalSamples, true, rt.debug,
+        PathStreams none{};
+        launch_accumulate(g.stream, none, owned, P, 0, 0, rt.totalSamples, true, rt.debug,
                           static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
     }
     HIP_OK(hipEventRecord(g.evB, g.stream));

@@ -143,9 +143,11 @@ __device__ __forceinline__ bool coop_inst_pretest(const DInst& I, f3 o, f3 rcpW,
     return !((tFar - n0) < -band);          // NaN / inf fall through to "enter"
 }
 
-// Ray source / result sink of one use of the walk (extend, shadow, test batch):
-//   bool load(uint32_t i, f3& o, f3& d)      -- false: this ray needs no traversal (finalised with a miss)
+// Ray source / result sink of one use of the walk (extend, shadow, both in one launch, test batch):
+//   bool load(uint32_t i, f3& o, f3& d, bool& anyHit)   -- false: this ray needs no traversal (finalised
+//                                                           with a miss); anyHit is read only when REC == 3
 //   void store(uint32_t i, const Best& b, f3 o, f3 d)
+// REC: 1 = every ray is a closest-hit ray, 2 = every ray is an any-hit (shadow) ray, 3 = per ray (policy).
 //
 // All 64 lanes of the wave call this; `counter` is a zero-initialised device word shared by the grid.
 template <int REC, class Policy>
@@ -167,6 +169,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     uint32_t par = 0;                                      // LDS ray slot of the current instance
     uint32_t markPrev = 0;                                 // qTail when the previous instance was left
     uint32_t finMark = 0; bool finishing = false;
+    bool anyHit = (REC == 2);                              // this lane's ray ends at its first accepted candidate
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     f3 rcpW = mk3(0.f, 0.f, 0.f); bool preOK = false; float oMax = 0.f;   // world-space pre-test state
     RayInst R;
@@ -204,7 +207,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                     B.slot = I._p0 + (low & COOP_LOCAL_MASK);
                     B.hit = true; B.inst = inst;
                     B.t = __uint_as_float((uint32_t)(key >> 32));
-                    if (REC == 1) {      // b1 / b2 recomputed with the arithmetic of the accepting test
+                    if (!anyHit) {       // b1 / b2 recomputed with the arithmetic of the accepting test
                         const f3 ro = mat4_mul3(I.inv, o.x, o.y, o.z, 1.0f);
                         const f3 rd = mat4_mul3(I.inv, d.x, d.y, d.z, 0.0f);
                         float t, b1, b2;
@@ -229,7 +232,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                         rayIdx = idx;
                         L.best[lane] = ~0ull;
                         sp = 0; par = 0; markPrev = qHead; finishing = false;
-                        const bool walk = pol.load(idx, o, d);
+                        bool ah = false;
+                        const bool walk = pol.load(idx, o, d, ah);
+                        anyHit = (REC == 2) || (REC == 3 && ah);
                         cur = walk ? (TAG_TLAS | 0u) : COOP_NONE;
                         rcpW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         const float amin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
@@ -282,7 +287,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             // every queued test of it lies before markPrev
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
             if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
-            if (REC == 2) { if (ready && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+            if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
             if (ready && cur != COOP_NONE) {
                 const uint32_t ci = cur & IDX_MASK;
                 const float4* ip = reinterpret_cast<const float4*>(A.insts + ci);
@@ -345,7 +350,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             coop_enqueue(A, L, lane, tagBits, cntR, stR, qHead, qTail, tmin, tmax);
             if (qTail - qHead >= 64u) {
                 coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
-                if (REC == 2) { if (cur != COOP_NONE && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+                if (REC != 1) { if (anyHit && cur != COOP_NONE && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
             }
             continue;
         }
