@@ -61,6 +61,26 @@ def algorithmic_bytes(top, inst, bot, tri, rays):
     return 16 * rays + 48 * top + 96 * inst + 48 * bot + 64 * tri
 
 
+def traversal_roofline(acc, visits, steps, depth):
+    """(kernel name, algorithmic bytes of its launches per frame, seconds of those launches over the timed region,
+    launches) of the dominant traversal kernel"""
+    if acc["ms_fused"] > 0.0:
+        # shadow(d) and extend(d+1) share one launch (k_fused_coop, D-1 launches per frame): its algorithmic bytes are
+        # those of the shadow rays of bounces 0..D-2 plus the closest-hit rays of bounces 1..D-1
+        prof, cnt = visits["profile"], visits["counts"]
+        D = prof.shape[0]
+
+        def bytes_of(d, cls):
+            v = prof[d, cls]
+            return algorithmic_bytes(v[0], v[1], v[2], v[3], cnt[d] if cls == 0 else cnt[d + 1])
+        return ("k_fused_coop", sum(bytes_of(d, 1) + bytes_of(d + 1, 0) for d in range(D - 1)), acc["ms_fused"] * 1e-3,
+                max(1, steps * (D - 1)))
+    rays = (acc["primary"] + acc["bounce"]) / steps
+    b = algorithmic_bytes(visits["visit_top_nodes"][0], visits["visit_instances"][0], visits["visit_bot_nodes"][0],
+                          visits["visit_triangles"][0], rays)
+    return ("k_extend", b, acc["ms_extend"] * 1e-3, max(1, acc["launches_extend"]))
+
+
 def cpu_baseline(scene, budget_s=20.0):
     """oracle (CPU port of the reference megakernel) on a strided pixel sample of the same frame"""
     import numpy as np
@@ -101,6 +121,7 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", type=int, default=-1, help="-1 auto, 0/1: shadow(d)+extend(d+1) in one launch")
     ap.add_argument("--also", default="", help="comma list of extra workloads to time (reported under 'also')")
     args = ap.parse_args()
 
@@ -132,6 +153,7 @@ def main():
         else:
             tdist.init_process_group(backend)
     plt = rd.Platform.GetPlatform(local_rank)
+    rd.SetOption("fuse", args.fuse)
 
     def run_workload(key, steps, warmup, want_roofline):
         cfg, label = WORKLOADS[key]
@@ -158,6 +180,8 @@ def main():
             st = rd.GetTraceStats()
             visits = {k: [int(getattr(st, k)[0]), int(getattr(st, k)[1])] for k in
                       ("visit_top_nodes", "visit_instances", "visit_bot_nodes", "visit_triangles")}
+            visits["profile"] = rd.GetVisitProfile(args.depth).astype(np.float64)     # [bounce][class][kind]
+            visits["counts"] = rd.GetBounceCounts(args.depth + 1).astype(np.float64)  # rays per bounce
             rd.SetOption("count_visits", 0)
         for _ in range(warmup):
             frame()
@@ -197,10 +221,11 @@ def main():
     for key in [k for k in args.also.split(",") if k]:
         sc2, _, a2, dt2, v2, lab2 = run_workload(key, max(2, args.steps // 2), 1, True)
         r2 = a2["primary"] + a2["bounce"] + a2["shadow"]
-        b2 = algorithmic_bytes(v2["visit_top_nodes"][0], v2["visit_instances"][0], v2["visit_bot_nodes"][0],
-                               v2["visit_triangles"][0], (a2["primary"] + a2["bounce"]) // max(2, args.steps // 2))
-        also[key] = {"workload": lab2, "Mrays_per_s": round(r2 / dt2 / 1e6, 2), "ms_per_frame": round(1e3 * dt2 / max(2, args.steps // 2), 3),
-                     "extend_algorithmic_GBps": round(b2 * max(2, args.steps // 2) / (a2["ms_extend"] * 1e-3) / 1e9, 1) if a2["ms_extend"] else None}
+        st2 = max(2, args.steps // 2)
+        kn2, b2, t2, _ = traversal_roofline(a2, v2, st2, args.depth)
+        also[key] = {"workload": lab2, "Mrays_per_s": round(r2 / dt2 / 1e6, 2), "ms_per_frame": round(1e3 * dt2 / st2, 3),
+                     "roofline_kernel": kn2, "roofline_achieved_GBps": round(b2 * st2 / t2 / 1e9, 1) if t2 else None,
+                     "roofline_frac": round(b2 * st2 / t2 / 1e9 / HBM_PEAK_GBS, 4) if t2 else None}
 
     if rank != 0:
         return
@@ -213,18 +238,7 @@ def main():
     bytes_shadow_frame = algorithmic_bytes(visits["visit_top_nodes"][1], visits["visit_instances"][1],
                                            visits["visit_bot_nodes"][1], visits["visit_triangles"][1], acc["shadow"] / steps)
     fused = acc["ms_fused"] > 0.0
-    if fused:
-        # small chunks: shadow(d) and extend(d+1) share one launch, so the dominant "kernel" is the traversal as a
-        # whole: all closest-hit + any-hit bytes over the time of every traversal launch of the timed region
-        kernel_name = "k_fused_coop + k_extend_coop + k_shadow_coop (all traversal launches)"
-        trav_s = (acc["ms_extend"] + acc["ms_shadow"] + acc["ms_fused"]) * 1e-3
-        roof_bytes = bytes_extend_frame + bytes_shadow_frame
-        launches = max(1, steps * (args.depth + 1))
-    else:
-        kernel_name = "k_extend"
-        trav_s = acc["ms_extend"] * 1e-3
-        roof_bytes = bytes_extend_frame
-        launches = max(1, acc["launches_extend"])
+    kernel_name, roof_bytes, trav_s, launches = traversal_roofline(acc, visits, steps, args.depth)
     achieved = roof_bytes * steps / trav_s / 1e9 if trav_s > 0 else 0.0
     pixels = args.width * args.height if world == 1 else None
     frame_bytes = bytes_extend_frame + bytes_shadow_frame + 184 * acc["hits"] / steps + (20 * pixels if pixels else 0)
@@ -250,13 +264,14 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": kernel_name,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None if fused else (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[0],
-            "traffic_source": None if fused else (pmc_traffic("rdx::k_extend_coop", args.workload) or (None, None))[1],
+            "traffic": (pmc_traffic("rdx::k_fused_coop" if fused else "rdx::k_extend_coop", args.workload) or (None, None))[0],
+            "traffic_source": (pmc_traffic("rdx::k_fused_coop" if fused else "rdx::k_extend_coop", args.workload) or (None, None))[1],
             "algorithmic_bytes_per_launch": int(roof_bytes * steps / launches),
             "avg_launch_ms": round(1e3 * trav_s / launches, 4),
             "launches": launches,
             "note": "achieved = reference-walk bytes (16/ray + 48/node + 96/instance visit + 64/triangle) of the k_extend "
-                    "launches in the timed region / their HIP-event time; traffic (PMC) see profiles/",
+                    "launches (fused: shadow rays of bounce d + closest-hit rays of bounce d+1 per launch) in the timed region / "
+                    "their HIP-event time; traffic (PMC) see profiles/",
         },
         "roofline_frame": {"algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2) if world == 1 else None,
                            "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if world == 1 else None,

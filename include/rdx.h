@@ -115,14 +115,21 @@ typedef struct rdx_trace_stats {
     uint32_t launches_extend, launches_shadow;
 } rdx_trace_stats;
 int         rdx_get_trace_stats(rdx_trace_stats* out);
+/* per-bounce visit counters of the last frame traced with "count_visits": out[8*d + 4*c + k], c = 0
+ * radiance / 1 shadow rays of bounce d, k = top nodes, instance visits, bottom nodes, triangle tests;
+ * returns the number of bounces written (<= max_bounces) */
+int         rdx_get_visit_profile(uint64_t* out, uint32_t max_bounces);
+/* out[d] = closest-hit rays traced at bounce d of the last frame; out[d+1] is also the number of hits,
+ * i.e. of shadow rays, of bounce d */
+int         rdx_get_bounce_counts(uint64_t* out, uint32_t n);
 /* 0 = per-stage HIP events off (default), 1 = on (adds launch gaps; for profiling only) */
 int         rdx_set_profiling(int on);
 /* knobs: "chunk_paths" (paths in flight per chunk), "count_visits" (0/1: also count node /
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 2 = wave-
  * cooperative (default), 1 = per-lane wide nodes, 0 = reference order; all three give identical
- * results, the option exists for A/B measurements and cross-checks), "fuse" (1 / 0 / -1 = auto: trace
- * the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch; auto enables
- * it below 4 M paths per chunk, where the fixed ramp + tail cost of a launch dominates), "overlap" and
+ * results, the option exists for A/B measurements and cross-checks), "fuse" (1 / -1 = on (default), 0 = off:
+ * trace the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch, which
+ * halves the fixed ramp + tail cost per bounce), "overlap" and
  * "groups" (experimental: second-stream overlap / concurrent sample groups; off by default) */
 int         rdx_set_option(const char* name, int64_t value);
 

@@ -66,6 +66,8 @@ SIGNATURES = {
     "rdx_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rdx_shard_pixel_count": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rdx_get_trace_stats": (C.c_int, [C.POINTER(rdx_trace_stats)]),
+    "rdx_get_visit_profile": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rdx_get_bounce_counts": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rdx_set_profiling": (C.c_int, [C.c_int]),
     "rdx_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "rdx_trace_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int,

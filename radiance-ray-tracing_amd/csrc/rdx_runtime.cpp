@@ -101,6 +101,8 @@ struct Context {
     int kernel = 2;                         // traversal kernel: 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
     rdx_trace_stats stats{};
+    uint32_t visitDepth = 0;                // bounces covered by hVisit after a count_visits frame
+    uint64_t bounceCounts[65] = {};         // [d] = closest-hit rays of bounce d, [d+1] = hits = shadow rays of bounce d (last frame)
 };
 Context g;
 
@@ -467,8 +469,8 @@ extern "C" int rdx_init(int device)
         HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&G.hCounts), 256 * sizeof(uint32_t), hipHostMallocDefault));
     }
     g.dCounts = g.groups[0].dCounts;
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dVisit), 8 * sizeof(unsigned long long)));
-    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hVisit), 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dVisit), 64 * 8 * sizeof(unsigned long long)));     // [bounce][class*4 + kind]
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hVisit), 64 * 8 * sizeof(unsigned long long), hipHostMallocDefault));
     g.initialized = true;
     return 0;
 }
@@ -765,6 +767,22 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail("kernel must be 0, 1 or 2"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
 }
+extern "C" int rdx_get_bounce_counts(uint64_t* out, uint32_t n)
+{
+    if (!out) return fail("null");
+    for (uint32_t d = 0; d < n && d < 65; ++d) out[d] = g.bounceCounts[d];
+    return 0;
+}
+
+extern "C" int rdx_get_visit_profile(uint64_t* out, uint32_t max_bounces)
+{
+    if (!out) return fail("null");
+    const uint32_t n = std::min(max_bounces, g.visitDepth);
+    for (uint32_t d = 0; d < n; ++d)
+        for (int k = 0; k < 8; ++k) out[8 * d + k] = g.hVisit[8 * d + k];
+    return (int)n;
+}
+
 extern "C" int rdx_get_trace_stats(rdx_trace_stats* out) { if (!out) return fail("null"); *out = g.stats; return 0; }
 
 extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint32_t height)
@@ -809,9 +827,10 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
     if (maxDepth > 62) return fail("TraceRays: depth %u exceeds the supported maximum of 62", maxDepth);
 
     std::memset(&g.stats, 0, sizeof g.stats);
+    std::memset(g.bounceCounts, 0, sizeof g.bounceCounts);
     g.stats.pixels = P;
     unsigned long long* visit = g.countVisits ? g.dVisit : nullptr;
-    if (visit) HIP_OK(hipMemsetAsync(g.dVisit, 0, 8 * sizeof(unsigned long long), g.stream));
+    if (visit) HIP_OK(hipMemsetAsync(g.dVisit, 0, 64 * 8 * sizeof(unsigned long long), g.stream));
 
     HIP_OK(hipEventRecord(g.evA, g.stream));
     const uint32_t batch = rt.batchSize;
@@ -832,7 +851,8 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         // Small chunks (multi-GPU shards, low resolutions): a traversal launch costs ~0.2 ms of ramp + tail
         // whatever its size (tools/trav_scale.py), so shadow(d) and extend(d+1) -- same ray count, disjoint
         // streams -- go into ONE cooperative launch: 9 traversal launches per depth-8 frame instead of 16.
-        const bool fuse = (g.fuse == 1 || (g.fuse == -1 && small)) && !visit && av.kernel == 2;
+        const bool fuse = g.fuse != 0 && !visit && av.kernel == 2;
+        (void)small;
         const bool overlap = g.overlap == 1 && !fuse && !visit;
         HIP_OK(hipEventRecord(g.evChunk, g.stream));          // everything before this chunk (previous accumulate) is done first
 
@@ -855,7 +875,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
             if (maxDepth == 0) launch_finalize_all(G.s0, gps[k], n0, P, sampleBase);
             if (maxDepth > 0) {
                 g_timer.begin(&g.stats.ms_extend, G.s0);
-                launch_extend(G.s0, av, gps[k], G.dCounts, n0, tmin, tmax, visit, G.dCounts + 64);
+                launch_extend(G.s0, av, gps[k], G.dCounts, n0, tmin, tmax, visit, G.dCounts + 64);     // visit row 0
                 g_timer.end(G.s0);
                 g.stats.launches_extend++;
             }
@@ -891,13 +911,14 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
                     ss = G.s1;
                 }
                 g_timer.begin(&g.stats.ms_shadow, ss);
-                launch_shadow(ss, av, sc, psShadow, G.dCounts + d + 1, n0, last, P, sampleBase, tmin, tmax, visit, G.dCounts + 128 + d);
+                launch_shadow(ss, av, sc, psShadow, G.dCounts + d + 1, n0, last, P, sampleBase, tmin, tmax, visit ? visit + 8 * d : nullptr,
+                              G.dCounts + 128 + d);
                 g_timer.end(ss);
                 if (overlap) HIP_OK(hipEventRecord(G.evShadow[d], G.s1));
                 g.stats.launches_shadow++;
                 if (!last) {
                     g_timer.begin(&g.stats.ms_extend, G.s0);
-                    launch_extend(G.s0, av, ps, G.dCounts + d + 1, n0, tmin, tmax, visit, G.dCounts + 64 + d + 1);
+                    launch_extend(G.s0, av, ps, G.dCounts + d + 1, n0, tmin, tmax, visit ? visit + 8 * (d + 1) : nullptr, G.dCounts + 64 + d + 1);
                     g_timer.end(G.s0);
                     g.stats.launches_extend++;
                 }
@@ -916,6 +937,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         HIP_OK(hipStreamSynchronize(g.stream));
         for (int k = 0; k < nGroups; ++k) {
             const uint32_t* hc = g.groups[k].hCounts;
+            for (uint32_t d = 0; d <= maxDepth && maxDepth; ++d) g.bounceCounts[d] += hc[d];
             if (maxDepth) g.stats.rays_primary += hc[0];
             for (uint32_t d = 1; d < maxDepth; ++d) g.stats.rays_bounce += hc[d];
             for (uint32_t d = 0; d < maxDepth; ++d) { g.stats.rays_shadow += hc[d + 1]; g.stats.closest_hits += hc[d + 1]; }
@@ -928,16 +950,21 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
                           static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
     }
     HIP_OK(hipEventRecord(g.evB, g.stream));
-    if (visit) HIP_OK(hipMemcpyAsync(g.hVisit, g.dVisit, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
+    if (visit) HIP_OK(hipMemcpyAsync(g.hVisit, g.dVisit, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));          // clFinish (radiance.cpp:261)
     HIP_OK(hipEventElapsedTime(&g.stats.ms_total, g.evA, g.evB));
     g_timer.resolve();
-    if (visit)
-        for (int c = 0; c < 2; ++c) {
-            g.stats.visit_top_nodes[c] = g.hVisit[c * 4 + 0]; g.stats.visit_instances[c] = g.hVisit[c * 4 + 1];
-            g.stats.visit_bot_nodes[c] = g.hVisit[c * 4 + 2]; g.stats.visit_triangles[c] = g.hVisit[c * 4 + 3];
-        }
+    g.visitDepth = 0;
+    if (visit) {
+        g.visitDepth = maxDepth;
+        for (uint32_t d = 0; d < maxDepth; ++d)
+            for (int c = 0; c < 2; ++c) {
+                const unsigned long long* v = g.hVisit + 8 * d + 4 * c;
+                g.stats.visit_top_nodes[c] += v[0]; g.stats.visit_instances[c] += v[1];
+                g.stats.visit_bot_nodes[c] += v[2]; g.stats.visit_triangles[c] += v[3];
+            }
+    }
     bScratch->version++; bImage->version++;
     return 0;
 }

@@ -295,6 +295,22 @@ def GetTraceStats():
     return st
 
 
+def GetVisitProfile(max_bounces=64):
+    """(bounces, 2, 4) uint64: per bounce, per ray class (radiance, shadow): top nodes, instance visits,
+    bottom nodes, triangle tests of the reference algorithm (after a frame traced with count_visits)"""
+    out = np.zeros(8 * max_bounces, np.uint64)
+    n = _lib.lib().rdx_get_visit_profile(out.ctypes.data, max_bounces)
+    if n < 0:
+        raise RadianceError(_lib.last_error())
+    return out[:8 * n].reshape(n, 2, 4)
+
+
+def GetBounceCounts(n=16):
+    out = np.zeros(n, np.uint64)
+    _check(_lib.lib().rdx_get_bounce_counts(out.ctypes.data, n))
+    return out
+
+
 def SetOption(name, value):
     _check(_lib.lib().rdx_set_option(name.encode(), int(value)))
 
