@@ -649,8 +649,17 @@ __device__ __forceinline__ void write_hit_record(const AccelView& A, const Trace
 // ---------------------------------------------------------------------------------------------
 // persistent wave-cooperative extend / shadow (production): see traverse_coop.h
 // ---------------------------------------------------------------------------------------------
+// glue shared by the policies that trace one ray per work item and need no shade step
+#define RDX_SINGLE_RAY_POLICY                                                                                   \
+    struct State {};                                                                                             \
+    static constexpr bool kShades = false;                                                                       \
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit, State&) const { return load(i, o, d, anyHit); } \
+    __device__ __forceinline__ int finish(uint32_t i, const Best& b, f3& o, f3& d, bool&, State&) const { store(i, b, o, d); return COOP_RELEASE; } \
+    __device__ __forceinline__ int shade(uint32_t, f3&, f3&, bool&, State&) const { return COOP_RELEASE; }
+
 struct ExtendPolicy {
     AccelView A; PathStreams ps;
+    RDX_SINGLE_RAY_POLICY
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
     {
         const float4 ro = ps.rayO[i], rd = ps.rayD[i];
@@ -667,6 +676,7 @@ struct ExtendPolicy {
 
 struct ShadowPolicy {
     AccelView A; PathStreams ps; f3 Ldir; uint32_t lastBounce, nPixels, sampleBase;
+    RDX_SINGLE_RAY_POLICY
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
     {
         const float4 so = ps.shO[i];
@@ -713,6 +723,7 @@ k_shadow_coop(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restr
 // (multi-GPU shards): see tools/trav_scale.py.
 struct FusedPolicy {
     ShadowPolicy sh; ExtendPolicy ex; uint32_t m;
+    RDX_SINGLE_RAY_POLICY
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
     {
         return i < m ? sh.load(i, o, d, anyHit) : ex.load(i - m, o, d, anyHit);
@@ -736,6 +747,7 @@ k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
 
 struct BatchPolicy {
     AccelView A; const float* o; const float* d; rdx_hit* out;
+    RDX_SINGLE_RAY_POLICY
     __device__ __forceinline__ bool load(uint32_t i, f3& ro, f3& rd, bool& anyHit) const
     {
         ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);

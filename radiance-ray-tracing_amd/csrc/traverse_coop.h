@@ -143,13 +143,23 @@ __device__ __forceinline__ bool coop_inst_pretest(const DInst& I, f3 o, f3 rcpW,
     return !((tFar - n0) < -band);          // NaN / inf fall through to "enter"
 }
 
-// Ray source / result sink of one use of the walk (extend, shadow, both in one launch, test batch):
-//   bool load(uint32_t i, f3& o, f3& d, bool& anyHit)   -- false: this ray needs no traversal (finalised
-//                                                           with a miss); anyHit is read only when REC == 3
-//   void store(uint32_t i, const Best& b, f3 o, f3 d)
+// Ray source / result sink of one use of the engine (extend, shadow, both in one launch, whole paths, test batch):
+//   typedef ... State;                                  per-lane state the policy keeps while a work item lives
+//   static constexpr bool kShades;                      does the policy use the shade step?
+//   bool load(i, o, d, anyHit, State&)                  first ray of work item i; false: nothing to trace, finish()
+//                                                       is called with a miss.  anyHit is honoured when REC == 3.
+//   int  finish(i, B, o, d, anyHit, State&)             the lane's ray is complete.  COOP_RELEASE: item done;
+//                                                       COOP_SHADE: wait for a shade step; COOP_NEWRAY: o, d, anyHit
+//                                                       now hold the item's next ray
+//   int  shade(i, o, d, anyHit, State&)                 converged shading step (COOP_RELEASE or COOP_NEWRAY)
 // REC: 1 = every ray is a closest-hit ray, 2 = every ray is an any-hit (shadow) ray, 3 = per ray (policy).
 //
 // All 64 lanes of the wave call this; `counter` is a zero-initialised device word shared by the grid.
+enum : int { COOP_RELEASE = 0, COOP_SHADE = 1, COOP_NEWRAY = 2 };
+#ifndef COOP_SHADE_BIAS
+#define COOP_SHADE_BIAS 8              // a shade step needs this many more waiting lanes than the busiest traversal step kind
+#endif
+
 template <int REC, class Policy>
 __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
                                               float tmin, float tmax, uint32_t* __restrict__ lds, uint32_t need)
@@ -170,6 +180,8 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     uint32_t markPrev = 0;                                 // qTail when the previous instance was left
     uint32_t finMark = 0; bool finishing = false;
     bool anyHit = (REC == 2);                              // this lane's ray ends at its first accepted candidate
+    bool needShade = false;                                // the lane's item waits for a shade step
+    typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
     f3 rcpW = mk3(0.f, 0.f, 0.f); bool preOK = false; float oMax = 0.f;   // world-space pre-test state
     RayInst R;
@@ -179,15 +191,16 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
 
     for (;;) {
         // ---- lanes whose walk has ended wait for their queued tests, then hand the result over ----
-        if (rayIdx != COOP_NONE && cur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }
+        if (rayIdx != COOP_NONE && cur == COOP_NONE && !finishing && !needShade) { finishing = true; finMark = qTail; }
         const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
         const bool isFree = (rayIdx == COOP_NONE);
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
         const unsigned long long workMask = __ballot(cur != COOP_NONE);
         const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
-        // Step selection is greedy: of the step kinds that lanes are waiting for (refill, top-level node,
-        // instance entry, BLAS node) the wave takes the one with the most lanes, so every step runs as
-        // converged as the moment allows and waiting lanes batch up instead of trickling through.
+        const int nShade = Policy::kShades ? __popcll(__ballot(needShade)) : 0;
+        // Step selection is greedy: of the step kinds that lanes are waiting for (refill, shade, top-level
+        // node, instance entry, BLAS node) the wave takes the one with the most lanes, so every step runs
+        // as converged as the moment allows and waiting lanes batch up instead of trickling through.
         const uint32_t tag = cur & TAG_MASK;
         const bool has = (cur != COOP_NONE);
         const bool isNode = has && tag == TAG_BLAS, isLeaf = has && tag == TAG_LEAF, isTop = has && tag == TAG_TLAS,
@@ -195,7 +208,20 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         const unsigned long long nodeMask = __ballot(isNode), topMask = __ballot(isTop), instMask = __ballot(isInst);
         const int nNode = __popcll(nodeMask), nTop = __popcll(topMask), nInst = __popcll(instMask);
         const int nMaxWork = max(nNode, max(nTop, nInst));
-        if (nIdle > 0 && (nIdle >= nMaxWork + COOP_IDLE_BIAS || workMask == 0ull)) {
+
+        // (re)start the walk of the ray now in o, d
+#define COOP_START_RAY(WALK) do {                                                                      \
+            L.best[lane] = ~0ull;                                                                      \
+            sp = 0; par = 0; markPrev = qHead; finishing = false; needShade = false;                   \
+            cur = (WALK) ? (TAG_TLAS | 0u) : COOP_NONE;                                                \
+            rcpW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                                            \
+            const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));                      \
+            const float amax_ = fmaxf(fmaxf(fabsf(rcpW.x), fabsf(rcpW.y)), fabsf(rcpW.z));             \
+            oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));                                   \
+            preOK = (amin_ > 1e-20f) && (amax_ < 1e20f) && (oMax < 1e20f);                             \
+        } while (0)
+
+        if (nIdle > 0 && (nIdle >= nMaxWork + COOP_IDLE_BIAS || (workMask == 0ull && nShade == 0))) {
             if (done) {
                 Best B;
                 B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
@@ -215,34 +241,44 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                         B.t = t; B.b1 = b1; B.b2 = b2;
                     }
                 }
-                pol.store(rayIdx, B, o, d);
-                rayIdx = COOP_NONE; finishing = false;
+                bool ah = anyHit;
+                const int act = pol.finish(rayIdx, B, o, d, ah, st);
+                finishing = false;
+                if (act == COOP_RELEASE) rayIdx = COOP_NONE;
+                else if (act == COOP_SHADE) needShade = true;
+                else { anyHit = (REC == 2) || (REC == 3 && ah); COOP_START_RAY(true); }
             }
             if (!exhausted) {
                 const bool want = (rayIdx == COOP_NONE);
                 const unsigned long long wm = __ballot(want);
                 const uint32_t cnt = (uint32_t)__popcll(wm);
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(counter, cnt);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base + cnt >= n) exhausted = true;
-                if (want) {
-                    const uint32_t idx = base + lanes_below(wm);
-                    if (idx < n) {
-                        rayIdx = idx;
-                        L.best[lane] = ~0ull;
-                        sp = 0; par = 0; markPrev = qHead; finishing = false;
-                        bool ah = false;
-                        const bool walk = pol.load(idx, o, d, ah);
-                        anyHit = (REC == 2) || (REC == 3 && ah);
-                        cur = walk ? (TAG_TLAS | 0u) : COOP_NONE;
-                        rcpW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        const float amin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-                        const float amax = fmaxf(fmaxf(fabsf(rcpW.x), fabsf(rcpW.y)), fabsf(rcpW.z));
-                        oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-                        preOK = (amin > 1e-20f) && (amax < 1e20f) && (oMax < 1e20f);
+                if (cnt) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(counter, cnt);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + cnt >= n) exhausted = true;
+                    if (want) {
+                        const uint32_t idx = base + lanes_below(wm);
+                        if (idx < n) {
+                            rayIdx = idx;
+                            bool ah = false;
+                            const bool walk = pol.load(idx, o, d, ah, st);
+                            anyHit = (REC == 2) || (REC == 3 && ah);
+                            COOP_START_RAY(walk);
+                        }
                     }
                 }
+            }
+            continue;
+        }
+        // ---- shade step: every lane whose closest-hit ray found something runs the hit shader together ----
+        if (Policy::kShades && nShade > 0 && (nShade >= nMaxWork + COOP_SHADE_BIAS || workMask == 0ull)) {
+            if (needShade) {
+                bool ah = false;
+                const int act = pol.shade(rayIdx, o, d, ah, st);
+                needShade = false;
+                if (act == COOP_RELEASE) rayIdx = COOP_NONE;
+                else { anyHit = (REC == 2) || (REC == 3 && ah); COOP_START_RAY(true); }
             }
             continue;
         }
@@ -358,6 +394,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
     }
 #undef COOP_POP
+#undef COOP_START_RAY
 }
 
 } // namespace rdx
