@@ -64,6 +64,13 @@ def algorithmic_bytes(top, inst, bot, tri, rays):
 def traversal_roofline(acc, visits, steps, depth):
     """(kernel name, algorithmic bytes of its launches per frame, seconds of those launches over the timed region,
     launches) of the dominant traversal kernel"""
+    if acc.get("ms_path", 0.0) > 0.0:
+        # whole paths in one launch per chunk (k_path_coop): every closest-hit and shadow walk of the frame + the
+        # closest-hit shading reads (184 B per hit, SURVEY 8d)
+        b = sum(algorithmic_bytes(visits["visit_top_nodes"][c], visits["visit_instances"][c], visits["visit_bot_nodes"][c],
+                                  visits["visit_triangles"][c], r)
+                for c, r in ((0, (acc["primary"] + acc["bounce"]) / steps), (1, acc["shadow"] / steps)))
+        return ("k_path_coop", b + 184 * acc["hits"] / steps, acc["ms_path"] * 1e-3, max(1, acc["launches_extend"]))
     if acc["ms_fused"] > 0.0:
         # shadow(d) and extend(d+1) share one launch (k_fused_coop, D-1 launches per frame): its algorithmic bytes are
         # those of the shadow rays of bounces 0..D-2 plus the closest-hit rays of bounces 1..D-1
@@ -122,6 +129,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse", type=int, default=-1, help="-1 auto, 0/1: shadow(d)+extend(d+1) in one launch")
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 library default, 0 staged wavefront, 1 whole paths in one persistent launch")
     ap.add_argument("--also", default="", help="comma list of extra workloads to time (reported under 'also')")
     args = ap.parse_args()
 
@@ -154,6 +162,8 @@ def main():
             tdist.init_process_group(backend)
     plt = rd.Platform.GetPlatform(local_rank)
     rd.SetOption("fuse", args.fuse)
+    if args.pipeline >= 0:
+        rd.SetOption("pipeline", args.pipeline)
 
     def run_workload(key, steps, warmup, want_roofline):
         cfg, label = WORKLOADS[key]
@@ -187,7 +197,7 @@ def main():
             frame()
         rd.SetProfiling(True)
         acc = dict(primary=0, bounce=0, shadow=0, hits=0, ms_extend=0.0, ms_shadow=0.0, ms_shade=0.0, ms_generate=0.0,
-                   ms_accumulate=0.0, ms_total=0.0, ms_fused=0.0, launches_extend=0)
+                   ms_accumulate=0.0, ms_total=0.0, ms_fused=0.0, ms_path=0.0, launches_extend=0)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -195,7 +205,7 @@ def main():
             st = rd.GetTraceStats()
             acc["primary"] += st.rays_primary; acc["bounce"] += st.rays_bounce; acc["shadow"] += st.rays_shadow
             acc["hits"] += st.closest_hits
-            for k in ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulate", "ms_total", "ms_fused"):
+            for k in ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulate", "ms_total", "ms_fused", "ms_path"):
                 acc[k] += getattr(st, k)
             acc["launches_extend"] += st.launches_extend
         sync()
@@ -264,8 +274,8 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": kernel_name,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": (pmc_traffic("rdx::k_fused_coop" if fused else "rdx::k_extend_coop", args.workload) or (None, None))[0],
-            "traffic_source": (pmc_traffic("rdx::k_fused_coop" if fused else "rdx::k_extend_coop", args.workload) or (None, None))[1],
+            "traffic": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[0],
+            "traffic_source": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[1],
             "algorithmic_bytes_per_launch": int(roof_bytes * steps / launches),
             "avg_launch_ms": round(1e3 * trav_s / launches, 4),
             "launches": launches,
@@ -276,7 +286,7 @@ def main():
         "roofline_frame": {"algorithmic_GBps": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2) if world == 1 else None,
                            "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if world == 1 else None,
                            "bytes_per_frame": int(frame_bytes)},
-        "stage_ms_per_frame": {k[3:]: round(acc[k] / steps, 4) for k in ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_fused", "ms_accumulate", "ms_total")},
+        "stage_ms_per_frame": {k[3:]: round(acc[k] / steps, 4) for k in ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_fused", "ms_path", "ms_accumulate", "ms_total")},
         "device": rd.Platform.device_name(),
     }
     if also:

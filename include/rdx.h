@@ -112,6 +112,7 @@ typedef struct rdx_trace_stats {
     uint64_t visit_top_nodes[2], visit_instances[2], visit_bot_nodes[2], visit_triangles[2];
     float    ms_total;                                 /* HIP-event time of the whole call */
     float    ms_generate, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_fused;  /* ms_fused: shadow(d)+extend(d+1) launches */
+    float    ms_path;                                  /* whole-path launches ("pipeline" 1) */
     uint32_t launches_extend, launches_shadow;
 } rdx_trace_stats;
 int         rdx_get_trace_stats(rdx_trace_stats* out);
@@ -127,7 +128,9 @@ int         rdx_set_profiling(int on);
 /* knobs: "chunk_paths" (paths in flight per chunk), "count_visits" (0/1: also count node /
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 2 = wave-
  * cooperative (default), 1 = per-lane wide nodes, 0 = reference order; all three give identical
- * results, the option exists for A/B measurements and cross-checks), "fuse" (1 / -1 = on (default), 0 = off:
+ * results, the option exists for A/B measurements and cross-checks), "pipeline" (0 = staged
+ * wavefront: one launch per stage per bounce (default); 1 = whole paths -- camera ray to path end -- in one
+ * persistent cooperative launch per sample chunk), "fuse" (1 / -1 = on (default), 0 = off:
  * trace the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch, which
  * halves the fixed ramp + tail cost per bounce), "overlap" and
  * "groups" (experimental: second-stream overlap / concurrent sample groups; off by default) */

@@ -71,6 +71,11 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
 // shadow(d) of `psShadow` and extend(d+1) of `psExtend` (its streams already swapped) in one cooperative launch
 void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& psShadow, const PathStreams& psExtend,
                   const uint32_t* mPtr, uint32_t mMax, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, uint32_t* counter);
+// whole paths (camera ray to path end) on the persistent cooperative engine, one launch per sample chunk;
+// tally[0] += closest-hit rays, tally[1] += shadow rays
+void launch_path(hipStream_t st, const AccelView& av, const SceneArgs& sc, const CameraArgs& cam, const PathStreams& ps,
+                 const uint32_t* owned, uint32_t nPixels, uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples,
+                 uint32_t maxDepth, uint32_t sampleBase, uint32_t* counter, unsigned long long* tally, float tmin, float tmax);
 void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* ownedPixels, uint32_t nPixels,
                        uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples, bool tonemap, uint32_t debug,
                        float* imageScratch, uint8_t* image);

@@ -745,6 +745,117 @@ k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
     traverse_coop<3>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
 }
 
+// ---------------------------------------------------------------------------------------------
+// whole paths on the cooperative engine: one launch per chunk of samples
+// ---------------------------------------------------------------------------------------------
+// A lane owns a (pixel, sample) path from the camera ray to its end: closest-hit walk -> shade step
+// (SBT dispatch, converged over the lanes waiting for it) -> any-hit walk of the shadow query -> next
+// bounce ..., all inside the persistent wave-cooperative engine.  No bounce ever synchronises the grid:
+// the per-launch ramp + tail of the staged pipeline (17 launches per depth-8 frame) is paid once, and the
+// path streams shrink to the few values that must survive a shadow walk (indexed by path, no compaction).
+// Arithmetic per value is that of the staged kernels (k_generate / k_shade / k_shadow), so frames are
+// bit-identical to the staged pipeline.
+struct PathPolicy {
+    AccelView A; SceneArgs sc; CameraArgs C; PathStreams ps; const uint32_t* owned;
+    uint32_t nPixels, sampleBegin, totalSamples, maxDepth, sampleBase;
+    f3 Ldir;
+    unsigned long long* tally;        // [0] closest-hit rays, [1] shadow rays (= closest hits)
+    struct State { uint32_t pixel, frameID, depth, triSlot, inst; float t, b1, b2; };
+    static constexpr bool kShades = true;
+
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit, State& st) const
+    {
+        const uint32_t sLocal = i / nPixels, slot = i - sLocal * nPixels;
+        st.pixel = owned ? owned[slot] : slot;
+        st.frameID = totalSamples + sampleBegin + sLocal;
+        st.depth = 0;
+        camera_ray(C, st.pixel, pcg3d(st.frameID, totalSamples, st.pixel), o, d);     // shader.cl:205
+        ps.thr[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(slot));
+        ps.col[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        anyHit = false;
+        atomicAdd(tally + 0, 1ull);
+        return true;
+    }
+    __device__ __forceinline__ void end_path(uint32_t i, const State& st, f3 c) const
+    {
+        store_sample(ps, nPixels, sampleBase, st.frameID, f2u(ps.thr[i].w), c);
+    }
+    // colour after this bounce is `c`: either the path ends or its next ray starts (shader.cl:233-260)
+    __device__ __forceinline__ int advance(uint32_t i, f3 c, f3& o, f3& d, bool& anyHit, State& st) const
+    {
+        if (st.depth + 1 >= maxDepth) { end_path(i, st, c); return COOP_RELEASE; }
+        const float4 tn = ps.nThr[i], no = ps.nRayO[i], nd = ps.nRayD[i];
+        ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
+        ps.thr[i] = make_float4(tn.x, tn.y, tn.z, ps.thr[i].w);
+        st.depth++;
+        o = mk3(no.x, no.y, no.z); d = mk3(nd.x, nd.y, nd.z); anyHit = false;
+        atomicAdd(tally + 0, 1ull);
+        return COOP_NEWRAY;
+    }
+    __device__ __forceinline__ int finish(uint32_t i, const Best& b, f3& o, f3& d, bool& anyHit, State& st) const
+    {
+        if (!anyHit) {
+            if (!b.hit) {            // miss shader, row 3; a primary miss shows its colour, a later one ends the path
+                Payload p; p.hit = false; p.color = mk3(0.f, 0.f, 0.f); p.colorOccluded = p.color;
+                callMiss(3, p);
+                const float4 c = ps.col[i];
+                end_path(i, st, st.depth == 0 ? p.color : mk3(c.x, c.y, c.z));
+                return COOP_RELEASE;
+            }
+            st.t = b.t; st.b1 = b.b1; st.b2 = b.b2; st.triSlot = b.slot; st.inst = b.inst;
+            return COOP_SHADE;
+        }
+        // the shadow query is answered: hit -> closest-hit row 2 `shadow`, miss -> row 4 `shadowMiss`
+        Payload sp; sp.hit = false;
+        if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[b.inst].SBTOffset + 2, sp, hh, sv, Ldir, 0, 0, 0, false); }
+        else callMiss(4, sp);
+        const float4 c = sp.hit ? ps.colSh[i] : ps.colLit[i];
+        return advance(i, mk3(c.x, c.y, c.z), o, d, anyHit, st);
+    }
+    __device__ __forceinline__ int shade(uint32_t i, f3& o, f3& d, bool& anyHit, State& st) const
+    {
+        const float4 thr = ps.thr[i], col = ps.col[i];
+        Payload p;
+        p.hit = false; p.wantsShadowRay = false;
+        p.color = mk3(0.f, 0.f, 0.f); p.colorOccluded = p.color;
+        p.nextFactor = mk3(1.f, 1.f, 1.f);
+        p.nextRayOrigin = o; p.nextRayDirection = d; p.shadowOrigin = o;
+        const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials};
+        HitInfo h;
+        fill_hit_info(A, st.inst, o, d, st.t, st.b1, st.b2, A.tris[st.triSlot].primID, h);
+        callHit((int)A.insts[st.inst].SBTOffset + 1, p, h, sv, d, st.frameID, st.pixel, st.depth, st.depth + 1 < maxDepth);
+        const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
+        if (!p.hit) {                // no closest-hit shader bound for this row: the raygen loop sees a miss
+            end_path(i, st, st.depth == 0 ? p.color : Cc);
+            return COOP_RELEASE;
+        }
+        const f3 lit = Cc + T * p.color;               // color += contribution * payload.color (shader.cl:240)
+        const f3 occ = Cc + T * p.colorOccluded;
+        const f3 tn = T * p.nextFactor;                // contribution *= payload.nextFactor    (shader.cl:241)
+        ps.nThr[i] = make_float4(tn.x, tn.y, tn.z, 0.0f);
+        ps.nRayO[i] = make_float4(p.nextRayOrigin.x, p.nextRayOrigin.y, p.nextRayOrigin.z, 0.0f);
+        ps.nRayD[i] = make_float4(p.nextRayDirection.x, p.nextRayDirection.y, p.nextRayDirection.z, 0.0f);
+        if (!p.wantsShadowRay) return advance(i, lit, o, d, anyHit, st);
+        ps.colLit[i] = make_float4(lit.x, lit.y, lit.z, 0.0f);
+        ps.colSh[i] = make_float4(occ.x, occ.y, occ.z, 0.0f);
+        o = p.shadowOrigin; d = Ldir; anyHit = true;   // traceRay(topLevel, 2, 4, hitPos, L, ...) (shader.cl:499-501)
+        atomicAdd(tally + 1, 1ull);
+        return COOP_NEWRAY;
+    }
+};
+
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_path_coop(AccelView A, SceneArgs sc, CameraArgs C, PathStreams ps, const uint32_t* __restrict__ owned, uint32_t nPixels,
+            uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples, uint32_t maxDepth, uint32_t sampleBase,
+            uint32_t* __restrict__ counter, unsigned long long* __restrict__ tally, float tmin, float tmax)
+{
+    const float* ld = sc.scene->lights[0].direction;
+    PathPolicy pol{A, sc, C, ps, owned, nPixels, sampleBegin, totalSamples, maxDepth, sampleBase,
+                   normalize3(mk3(-ld[0], -ld[1], -ld[2])), tally};
+    traverse_coop<3>(A, pol, nPixels * sampleCount, counter, tmin, tmax,
+                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
+}
+
 struct BatchPolicy {
     AccelView A; const float* o; const float* d; rdx_hit* out;
     RDX_SINGLE_RAY_POLICY
@@ -936,6 +1047,17 @@ void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
     size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
     hipLaunchKernelGGL(k_fused_coop, dim3(coop_blocks(2u * mMax, th, lds)), dim3(th), lds, st, av, sc, psShadow, psExtend, mPtr,
                        counter, nPixels, sampleBase, tmin, tmax);
+}
+
+void launch_path(hipStream_t st, const AccelView& av, const SceneArgs& sc, const CameraArgs& cam, const PathStreams& ps,
+                 const uint32_t* owned, uint32_t nPixels, uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples,
+                 uint32_t maxDepth, uint32_t sampleBase, uint32_t* counter, unsigned long long* tally, float tmin, float tmax)
+{
+    const uint64_t n = (uint64_t)nPixels * sampleCount;
+    if (!n) return;
+    size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
+    hipLaunchKernelGGL(k_path_coop, dim3(coop_blocks((uint32_t)n, th, lds)), dim3(th), lds, st, av, sc, cam, ps, owned, nPixels,
+                       sampleBegin, sampleCount, totalSamples, maxDepth, sampleBase, counter, tally, tmin, tmax);
 }
 
 void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* owned, uint32_t nPixels, uint32_t sampleBegin,

@@ -92,7 +92,8 @@ struct Context {
     float4* sampleColor = nullptr;
     uint32_t* dCounts = nullptr;            // = groups[0].dCounts (test seams)
     int groupsOpt = 1;                      // sample groups in flight (experimental): 1..4
-    int fuse = -1;                          // shadow(d) + extend(d+1) in one launch: 1 on, 0 off, -1 auto (small chunks)
+    int fuse = -1;                          // shadow(d) + extend(d+1) in one launch: 1 / -1 on, 0 off
+    int pathMode = 0;                       // 0 = staged wavefront (launch per stage per bounce), 1 = whole paths in one launch
     unsigned long long* dVisit = nullptr;   // 8 words
     unsigned long long* hVisit = nullptr;   // pinned
     // options
@@ -763,6 +764,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "count_visits")) { g.countVisits = value != 0; return 0; }
     if (!strcmp(name, "groups")) { if (value < 1 || value > Context::MAX_GROUPS) return fail("groups must be 1..4"); g.groupsOpt = (int)value; return 0; }
     if (!strcmp(name, "overlap")) { if (value < 0 || value > 1) return fail("overlap must be 0 or 1"); g.overlap = (int)value; return 0; }
+    if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail("kernel must be 0, 1 or 2"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
@@ -855,6 +857,33 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         (void)small;
         const bool overlap = g.overlap == 1 && !fuse && !visit;
         HIP_OK(hipEventRecord(g.evChunk, g.stream));          // everything before this chunk (previous accumulate) is done first
+
+        if (g.pathMode == 1 && !visit && av.kernel == 2 && maxDepth > 0) {
+            // ---- whole paths in one persistent launch (k_path_coop) + accumulate ----
+            Context::Group& G = g.groups[0];
+            const uint32_t n0 = sc_n * P;
+            if (ensure_group(G, n0)) return -1;
+            G.ps.sampleColor = g.sampleColor;
+            std::memset(G.hCounts, 0, 256 * sizeof(uint32_t));
+            HIP_OK(hipMemcpyAsync(G.dCounts, G.hCounts, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+            unsigned long long* tally = reinterpret_cast<unsigned long long*>(G.dCounts + 192);     // 8-byte aligned words 192..195
+            g_timer.begin(&g.stats.ms_path);
+            launch_path(g.stream, av, sc, C, G.ps, owned, P, s0, sc_n, rt.totalSamples, maxDepth, sampleBase, G.dCounts + 64, tally, tmin, tmax);
+            g_timer.end();
+            g_timer.begin(&g.stats.ms_accumulate);
+            launch_accumulate(g.stream, G.ps, owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
+                              static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
+            g_timer.end();
+            HIP_OK(hipMemcpyAsync(G.hCounts, G.dCounts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+            HIP_OK(hipStreamSynchronize(g.stream));
+            const unsigned long long* ht = reinterpret_cast<const unsigned long long*>(G.hCounts + 192);
+            g.stats.rays_primary += n0;
+            g.stats.rays_bounce += ht[0] - n0;
+            g.stats.rays_shadow += ht[1];
+            g.stats.closest_hits += ht[1];
+            g.stats.launches_extend++;
+            continue;
+        }
 
         uint32_t gBegin[Context::MAX_GROUPS + 1];
         for (int k = 0; k <= nGroups; ++k) gBegin[k] = (uint32_t)((uint64_t)sc_n * k / nGroups);

@@ -398,22 +398,22 @@ def test_full_size_kernels_agree_bitwise(mods, cfg):
 
 
 def test_fused_and_split_schedules_identical(mods):
-    """shadow(d) + extend(d+1) traced by one fused launch (automatic for small chunks) or by two launches
-    give bit-identical frames; so do 2 concurrent sample groups and the two-stream overlap"""
+    """shadow(d) + extend(d+1) traced by one fused launch or by two launches give bit-identical frames; so
+    do 2 concurrent sample groups, the two-stream overlap, and the whole-path pipeline (one launch per chunk)"""
     rd, scenes = mods
     s = scenes.c2_atrium(160, 90, spp=4, depth=6, detail=0.2)
     dev = scenes.DeviceScene(s)
     outs = []
     try:
-        for opts in ({"fuse": 1}, {"fuse": 0}, {"fuse": 0, "overlap": 1}, {"fuse": 0, "groups": 2}):
-            for k, v in {"fuse": -1, "overlap": 0, "groups": 1, **opts}.items():
+        for opts in ({"fuse": 1}, {"fuse": 0}, {"fuse": 0, "overlap": 1}, {"fuse": 0, "groups": 2}, {"pipeline": 1}):
+            for k, v in {"fuse": -1, "overlap": 0, "groups": 1, "pipeline": 0, **opts}.items():
                 rd.SetOption(k, v)
             dev.set_rtprop(totalSamples=0); dev.clear_scratch()
             dev.render()
             st = rd.GetTraceStats()
             outs.append((dev.read_scratch().copy(), st.rays_bounce, st.rays_shadow))
     finally:
-        rd.SetOption("fuse", -1); rd.SetOption("overlap", 0); rd.SetOption("groups", 1)
+        rd.SetOption("fuse", -1); rd.SetOption("overlap", 0); rd.SetOption("groups", 1); rd.SetOption("pipeline", 0)
     for o in outs[1:]:
         assert np.array_equal(_bits(outs[0][0]), _bits(o[0])) and outs[0][1:] == o[1:]
 
