@@ -15,7 +15,8 @@ struct AccelView {                 // derived traversal layout (see rdx_types.h)
     const DNode* bnodes;
     const DTri*  tris;
     const DWide* wide;             // wide BLAS nodes (production kernels)
-    uint32_t stackNeed;            // worst-case stack entries of an exhaustive DFS
+    uint32_t stackNeed;            // worst-case stack entries of an exhaustive DFS (per-lane kernels)
+    uint32_t coopNeed;             // the same for the wave-cooperative kernel (see derive_accel)
     uint32_t kernel;               // 2 = wave-cooperative (default), 1 = per-lane wide, 0 = reference order
 };
 

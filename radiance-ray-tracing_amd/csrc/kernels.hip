@@ -650,6 +650,12 @@ __device__ __forceinline__ void write_hit_record(const AccelView& A, const Trace
 // persistent wave-cooperative extend / shadow (production): see traverse_coop.h
 // ---------------------------------------------------------------------------------------------
 // glue shared by the policies that trace one ray per work item and need no shade step
+// 5 waves per SIMD: the register allocator is held to 96 VGPRs (no spills; left alone it takes ~107 once the steal
+// step is compiled in and residency drops to 4)
+#ifndef COOP_WPE
+#define COOP_WPE 5
+#endif
+#define COOP_BOUNDS __launch_bounds__(RDX_BLOCK, COOP_WPE)
 #define RDX_SINGLE_RAY_POLICY                                                                                   \
     struct State {};                                                                                             \
     static constexpr bool kShades = false;                                                                       \
@@ -700,20 +706,20 @@ struct ShadowPolicy {
     }
 };
 
-__global__ void __launch_bounds__(RDX_BLOCK)
+__global__ void COOP_BOUNDS
 k_extend_coop(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
 {
     ExtendPolicy pol{A, ps};
-    traverse_coop<1>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
+    traverse_coop<1>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
-__global__ void __launch_bounds__(RDX_BLOCK)
+__global__ void COOP_BOUNDS
 k_shadow_coop(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
               uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
     const float* ld = sc.scene->lights[0].direction;
     ShadowPolicy pol{A, ps, normalize3(mk3(-ld[0], -ld[1], -ld[2])), lastBounce, nPixels, sampleBase};   // shader.cl:471-476
-    traverse_coop<2>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
+    traverse_coop<2>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
 // shadow(d) and extend(d+1) in ONE launch: both have counts[d+1] rays and touch disjoint streams
@@ -734,7 +740,7 @@ struct FusedPolicy {
     }
 };
 
-__global__ void __launch_bounds__(RDX_BLOCK)
+__global__ void COOP_BOUNDS
 k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
              uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
@@ -742,7 +748,7 @@ k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
     const uint32_t m = *mPtr;
     FusedPolicy pol{ShadowPolicy{A, psShadow, normalize3(mk3(-ld[0], -ld[1], -ld[2])), 0u, nPixels, sampleBase},
                     ExtendPolicy{A, psExtend}, m};
-    traverse_coop<3>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
+    traverse_coop<3>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -853,7 +859,7 @@ k_path_coop(AccelView A, SceneArgs sc, CameraArgs C, PathStreams ps, const uint3
     PathPolicy pol{A, sc, C, ps, owned, nPixels, sampleBegin, totalSamples, maxDepth, sampleBase,
                    normalize3(mk3(-ld[0], -ld[1], -ld[2])), tally};
     traverse_coop<3>(A, pol, nPixels * sampleCount, counter, tmin, tmax,
-                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
+                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
 struct BatchPolicy {
@@ -875,12 +881,12 @@ struct BatchPolicy {
 };
 
 template <int REC>
-__global__ void __launch_bounds__(RDX_BLOCK)
+__global__ void COOP_BOUNDS
 k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
                    float tmin, float tmax, rdx_hit* __restrict__ out)
 {
     BatchPolicy pol{A, o, d, out};
-    traverse_coop<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.stackNeed), A.stackNeed);
+    traverse_coop<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -983,17 +989,36 @@ void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& p
 // threads per block for the cooperative kernels: per-wave LDS = stack + queue + ray table
 static inline uint32_t coop_threads(uint32_t need, size_t& ldsBytes)
 {
-    const size_t perWave = (size_t)coop_words_per_wave(need) * 4;
-    uint32_t threads = RDX_BLOCK;
-    while (threads > 64 && perWave * (threads / 64) > 52 * 1024) threads >>= 1;
+    // experiment knobs (tools/occupancy_probe.sh): RDX_COOP_THREADS = block size, RDX_COOP_LDS_PAD = extra LDS bytes per
+    // wave (lowers the residency the LDS allows)
+    static const int envThreads = std::getenv("RDX_COOP_THREADS") ? std::atoi(std::getenv("RDX_COOP_THREADS")) : 0;
+    static const int envPad = std::getenv("RDX_COOP_LDS_PAD") ? std::atoi(std::getenv("RDX_COOP_LDS_PAD")) : 0;
+    const size_t perWave = (size_t)coop_words_per_wave(need) * 4 + (size_t)envPad;
+    // Residency is LDS-bound (tools/occupancy_probe.sh: frame time falls steadily up to the 5 waves / SIMD the
+    // registers allow), so take the block size -- 4 or 2 waves -- that packs the most waves into a CU's 160 KB.
+    uint32_t threads = 64;
+    if (envThreads >= 64) {
+        threads = (uint32_t)envThreads;
+        while (threads > 64 && perWave * (threads / 64) > 64 * 1024) threads >>= 1;
+    } else {
+        uint32_t best = 0;
+        for (uint32_t t : {256u, 128u}) {
+            const size_t blk = perWave * (t / 64);
+            if (blk > 64 * 1024) continue;
+            const uint32_t waves = std::min<uint32_t>((uint32_t)((160 * 1024) / blk) * (t / 64), 4u * COOP_WPE);
+            if (waves > best) { best = waves; threads = t; }
+        }
+    }
     ldsBytes = perWave * (threads / 64);
     return threads;
 }
 // persistent grid: enough blocks to fill every CU at the LDS-limited residency, never more than the work
 static inline uint32_t coop_blocks(uint32_t nMax, uint32_t threads, size_t ldsBytes)
 {
-    const uint32_t perCU = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(ldsBytes, 1), 2048 / threads));
-    return std::min(blocks_for(nMax, threads), 256u * perCU);
+    const uint32_t perCU = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(ldsBytes, 1), (64u * 4u * COOP_WPE) / threads));
+    // small launches: enough waves that each is handed COOP_MIN_QUOTA rays (its other lanes help, traverse_coop.h)
+    const uint64_t spread = COOP_STEAL ? (uint64_t)nMax * (64u / COOP_MIN_QUOTA) : nMax;
+    return (uint32_t)std::min<uint64_t>((spread + threads - 1) / threads, 256u * perCU);
 }
 
 void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,
@@ -1001,7 +1026,7 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
 {
     if (!nMax) return;
     if (!visit && av.kernel == 2) {
-        size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
+        size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
         hipLaunchKernelGGL(k_extend_coop, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
         return;
     }
@@ -1026,7 +1051,7 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
 {
     if (!nMax) return;
     if (!visit && av.kernel == 2) {
-        size_t ldsc; const uint32_t thc = coop_threads(av.stackNeed, ldsc);
+        size_t ldsc; const uint32_t thc = coop_threads(av.coopNeed, ldsc);
         hipLaunchKernelGGL(k_shadow_coop, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
                            lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
         return;
@@ -1044,7 +1069,7 @@ void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
                   const uint32_t* mPtr, uint32_t mMax, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, uint32_t* counter)
 {
     if (!mMax) return;
-    size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
+    size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
     hipLaunchKernelGGL(k_fused_coop, dim3(coop_blocks(2u * mMax, th, lds)), dim3(th), lds, st, av, sc, psShadow, psExtend, mPtr,
                        counter, nPixels, sampleBase, tmin, tmax);
 }
@@ -1055,7 +1080,7 @@ void launch_path(hipStream_t st, const AccelView& av, const SceneArgs& sc, const
 {
     const uint64_t n = (uint64_t)nPixels * sampleCount;
     if (!n) return;
-    size_t lds; const uint32_t th = coop_threads(av.stackNeed, lds);
+    size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
     hipLaunchKernelGGL(k_path_coop, dim3(coop_blocks((uint32_t)n, th, lds)), dim3(th), lds, st, av, sc, cam, ps, owned, nPixels,
                        sampleBegin, sampleCount, totalSamples, maxDepth, sampleBase, counter, tally, tmin, tmax);
 }
@@ -1091,7 +1116,7 @@ void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, con
 {
     if (!n) return;
     if (!visit && mode == 0 && av.kernel == 2) {
-        size_t ldsc; const uint32_t thc = coop_threads(av.stackNeed, ldsc);
+        size_t ldsc; const uint32_t thc = coop_threads(av.coopNeed, ldsc);
         const dim3 gc(coop_blocks(n, thc, ldsc));
         if (rec == 2) hipLaunchKernelGGL(k_trace_batch_coop<2>, gc, dim3(thc), ldsc, st, av, o, d, n, counter, tmin, tmax, out);
         else hipLaunchKernelGGL(k_trace_batch_coop<1>, gc, dim3(thc), ldsc, st, av, o, d, n, counter, tmin, tmax, out);

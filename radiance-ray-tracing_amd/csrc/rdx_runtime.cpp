@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -32,7 +33,8 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     uint64_t version = ~0ull;
     DNode* tnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
     DWide* wide = nullptr;
-    uint32_t stackNeed = 1;
+    uint32_t stackNeed = 1;            // per-lane kernels (reference order: left child followed, right child pushed)
+    uint32_t coopNeed = 1;             // wave-cooperative kernel (leaf children are never pushed, smaller subtree first)
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
     void release()
     {
@@ -177,9 +179,10 @@ int derive_accel(rdx_buffer_s* tb)
     std::vector<DTri> dTri;
     std::vector<DWide> dW;
     std::vector<DInst> dI(nInst);
-    struct BlasInfo { uint32_t nodeBase; uint32_t need; uint32_t triBase; uint32_t rootDesc0, rootDesc1; float rootMin[3], rootMax[3]; };
+    struct BlasInfo { uint32_t nodeBase; uint32_t need; uint32_t coopNeed; uint32_t triBase; uint32_t rootDesc0, rootDesc1; float rootMin[3], rootMax[3]; };
     bool coopOK = nInst <= 1024;
     uint32_t maxLeafChunks = 0;             // extra stack entries an oversized (> 8 triangle) leaf can push
+    uint32_t maxLeafTris = 0;
     std::map<uint32_t, BlasInfo> blasAt;    // byte offset -> merged-array base
     for (uint32_t k = 0; k < nInst; ++k) {
         const BlobInst& bi = binst[k];
@@ -208,6 +211,7 @@ int derive_accel(rdx_buffer_s* tb)
                 if (bn[i].w0 & LEAF_BIT) {
                     if ((uint64_t)bn[i].w1 + (bn[i].w0 & 0x7fffffffu) > nTris) return fail("BLAS blob: leaf range out of bounds");
                     maxLeafChunks = std::max(maxLeafChunks, 2u * (((bn[i].w0 & 0x7fffffffu) + 7u) / 8u));
+                    maxLeafTris = std::max(maxLeafTris, bn[i].w0 & 0x7fffffffu);
                     d.w1 = bn[i].w1 + triBase;
                 } else {
                     if (bn[i].w0 >= nNodes || bn[i].w1 >= nNodes) return fail("BLAS blob: child index out of range");
@@ -237,16 +241,30 @@ int derive_accel(rdx_buffer_s* tb)
                 else { d0 = wideBase + wideIdx[c]; d1 = 0; }
             };
             dW.resize(wideBase + nInner);
-            for (uint32_t i = 0; i < nNodes; ++i) {
+            // Stack need of the wide walk: a leaf child is queued, never pushed; of two inner children one is followed
+            // and the other pushed.  The visiting order is free, so the child with the SMALLER need goes
+            // into the "followed" (left) half of the record: need = max(1 + smaller, larger) instead of
+            // max(1 + left, right).  Children have larger indices than their parent (DFS pre-order).
+            std::vector<uint32_t> cneed(nNodes, 0), wneed(nNodes, 0);   // wneed: per-lane wide kernel on the same records (pushes leaves too)
+            for (uint32_t i = nNodes; i-- > 0;) {
                 if (bn[i].w0 & LEAF_BIT) continue;
+                uint32_t a = bn[i].w0, b = bn[i].w1;
+                const bool la = bn[a].w0 & LEAF_BIT, lb = bn[b].w0 & LEAF_BIT;
+                if (!la && !lb) {
+                    if (cneed[b] < cneed[a]) std::swap(a, b);
+                    cneed[i] = std::max(1u + cneed[a], cneed[b]);
+                } else {
+                    cneed[i] = la ? (lb ? 0u : cneed[b]) : cneed[a];
+                }
+                wneed[i] = std::max(1u + wneed[a], wneed[b]);
                 DWide& w = dW[wideBase + wideIdx[i]];
-                const BlobNode& L = bn[bn[i].w0]; const BlobNode& Rn = bn[bn[i].w1];
+                const BlobNode& L = bn[a]; const BlobNode& Rn = bn[b];
                 for (int k = 0; k < 3; ++k) { w.lmin[k] = L.bottom[k]; w.lmax[k] = L.top[k]; w.rmin[k] = Rn.bottom[k]; w.rmax[k] = Rn.top[k]; }
-                desc(bn[i].w0, w.ld0, w.ld1);
-                desc(bn[i].w1, w.rd0, w.rd1);
+                desc(a, w.ld0, w.ld1);
+                desc(b, w.rd0, w.rd1);
             }
             BlasInfo info{};
-            info.nodeBase = nodeBase; info.need = blas_need(bn, 0); info.triBase = triBase;
+            info.nodeBase = nodeBase; info.need = std::max(blas_need(bn, 0), wneed[0]); info.coopNeed = cneed[0]; info.triBase = triBase;
             if (nTris > (1u << 22)) coopOK = false;
             desc(0, info.rootDesc0, info.rootDesc1);
             for (int k = 0; k < 3; ++k) { info.rootMin[k] = bn[0].bottom[k]; info.rootMax[k] = bn[0].top[k]; }
@@ -288,20 +306,29 @@ int derive_accel(rdx_buffer_s* tb)
         }
     }
     // stack need: TLAS part
-    std::vector<uint32_t> needT(nTop, 0);
+    // (cooperative kernel: the instances of a top-level leaf are pushed as 16-bit masks, one entry per 16 instances,
+    //  and the entry being consumed is pushed back while one of its instances is walked)
+    std::vector<uint32_t> needT(nTop, 0), needC(nTop, 0);
     for (uint32_t i = nTop; i-- > 0;) {
         const BlobNode& n = tnodes[i];
         if (n.w0 & LEAF_BIT) {
             const uint32_t cnt = n.w0 & 0x7fffffffu;
-            uint32_t mx = 0;
-            for (uint32_t k = 0; k < cnt; ++k) mx = std::max(mx, blasAt[binst[n.w1 + k].instanceOffset].need);
+            uint32_t mx = 0, mxc = 0;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const BlasInfo& bi = blasAt[binst[n.w1 + k].instanceOffset];
+                mx = std::max(mx, bi.need); mxc = std::max(mxc, bi.coopNeed);
+            }
             needT[i] = (cnt ? cnt - 1 : 0) + mx;
+            needC[i] = (cnt + 15u) / 16u + mxc;
         } else {
             needT[i] = std::max(1u + needT[n.w0], needT[n.w1]);   // children have larger indices (DFS pre-order)
+            needC[i] = std::max(1u + needC[n.w0], needC[n.w1]);
         }
     }
     auto ac = std::make_unique<AccelCache>();
     ac->stackNeed = std::max(1u, needT[0]) + 1u + maxLeafChunks;
+    // oversized leaves are cut into 8-triangle work items: all but the first piece of each child are pushed
+    ac->coopNeed = std::max(1u, needC[0]) + 1u + 2u * ((std::max(maxLeafTris, 1u) + 7u) / 8u - 1u);
     if (ac->stackNeed > 2560) return fail("BVH too deep for the LDS traversal stack (%u entries)", ac->stackNeed);
     auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
@@ -316,6 +343,9 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->tris, dTri));
     HIP_OK(up(ac->wide, dW));
     ac->coopOK = coopOK && dTri.size() < (1u << 26);
+    if (std::getenv("RDX_VERBOSE"))
+        std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u)\n",
+                     nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed);
     ac->version = tb->version;
     if (tb->accel) tb->accel->release();
     tb->accel = std::move(ac);
@@ -329,6 +359,7 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.wide = tb->accel->wide;
     v.kernel = (g.kernel == 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
     v.stackNeed = tb->accel->stackNeed;
+    v.coopNeed = tb->accel->coopNeed;
     return v;
 }
 

@@ -32,6 +32,17 @@
 //               same wave is still walking.  The wave leaves when the counter is exhausted, every lane
 //               is idle and the queue is empty -- an exit every wave reaches.
 //
+//   steal step  subtree sharing inside the wave.  Because nothing is culled by the best t, the subtrees on a
+//               lane's stack are independent pieces of work whose only output is the atomic-min key of
+//               the ray's owner -- so ANY lane may walk them.  Once the wave cannot get new rays (global
+//               counter exhausted) or was handed fewer than 64 rays (small launches are spread over the whole
+//               chip, `quota` rays per wave), free lanes take the bottom entry of a busy lane's stack (the
+//               largest pending subtree) and walk it on behalf of that ray: the world ray comes over by
+//               lane shuffles, the object-space ray by copying the donor's LDS ray slot, candidates go to
+//               best[owner], and the owner hands its result over only when its helper count is back to 0.
+//               Helpers donate in turn, so one long ray spreads over the wave in a few steps and the tail of a
+//               launch is bounded by the wave's remaining WORK / 64 instead of by its longest ray.
+//
 // Any-hit (shadow) rays use the same machinery and drop their remaining work as soon as a candidate
 // has been published.
 //
@@ -41,19 +52,41 @@
 
 namespace rdx {
 
-#define COOP_QCAP 512u                 // queue ring capacity in entries (power of two)
+#ifndef COOP_QCAP
+#define COOP_QCAP 512u                 // queue ring capacity in entries (power of two, >= 256)
+#endif
 #define COOP_LANE_SHIFT 26u            // queue entry = owner lane << 26 | ray-slot bit << 25 | absolute triangle slot
 #define COOP_PAR_SHIFT 25u
 #define COOP_SLOT_MASK ((1u << 25) - 1u)
 #define COOP_INST_SHIFT 22u            // key low word = instance slot << 22 | BLAS-local triangle slot
 #define COOP_LOCAL_MASK ((1u << 22) - 1u)
 #define COOP_NONE 0xffffffffu
-#define COOP_RAY_WORDS 8u              // per lane per slot: o.xyz d.xyz instance triBase
+#define COOP_RAY_WORDS 7u              // per lane per slot: o.xyz d.xyz (object space), instance slot | owner lane << 16
 #ifndef COOP_IDLE_BIAS
 #define COOP_IDLE_BIAS 16              // a refill step needs this many more idle lanes than the busiest work kind has (tuned: profiles/)
 #endif
 
-__host__ __device__ inline uint32_t coop_words_per_wave(uint32_t need) { return need * 64u + COOP_QCAP + 2u * COOP_RAY_WORDS * 64u + 128u; }
+#ifndef COOP_STEAL
+#define COOP_STEAL 1                   // subtree sharing inside the wave (steal step)
+#endif
+#ifndef COOP_MIN_QUOTA
+#define COOP_MIN_QUOTA 64u             // rays handed to a wave per refill, at least.  < 64 spreads small launches over more waves whose
+                                       // other lanes help: faster below ~16 k rays, slower above (tools/gpu_variants.sh) -- off
+#endif
+#ifndef COOP_STEAL_MIN
+#define COOP_STEAL_MIN 4               // a steal step needs this many (stealer, donor) pairs, or a quarter of the walking lanes
+#endif
+#ifndef COOP_TAIL_MIN
+#define COOP_TAIL_MIN 4                // while stealing: finished lanes are handed over as soon as this many wait
+#endif
+#define COOP_OWNER_SHIFT 16u           // ray slot word 6 = instance slot | owner lane << 16
+#define COOP_RESUME (1u << 29)         // TAG_INST work item of a helper: enter the instance, then continue with the stolen entry on the stack
+// TAG_INST work item = up to 16 instances of one top-level leaf: first instance slot (13 bits) | 16-bit mask of the
+// instances still to enter << 13.  One stack entry per 16 instances instead of one per instance.
+#define COOP_IMASK_SHIFT 13u
+#define COOP_IFIRST_MASK ((1u << COOP_IMASK_SHIFT) - 1u)
+
+__host__ __device__ inline uint32_t coop_words_per_wave(uint32_t need) { return need * 64u + COOP_QCAP + 2u * COOP_RAY_WORDS * 64u + 128u + 64u; }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
 {
@@ -65,6 +98,7 @@ struct CoopLds {
     uint32_t* queue;                 // [COOP_QCAP]
     float* ray;                      // [2 slots][8 words][64 lanes]
     unsigned long long* best;        // [64]
+    uint32_t* pend;                  // [64] helpers still walking for the ray owned by this lane
 };
 
 // branch-free Möller–Trumbore (radiance.cl:211-251) + the accept window of radiance.cl:90-91
@@ -93,23 +127,25 @@ __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds
     const uint32_t n = min(64u, qTail - qHead);
     if (lane < n) {
         const uint32_t e = L.queue[(qHead + lane) & (COOP_QCAP - 1u)];
-        const uint32_t owner = e >> COOP_LANE_SHIFT, slot = e & COOP_SLOT_MASK;
-        const float* rs = L.ray + ((e >> COOP_PAR_SHIFT) & 1u) * (COOP_RAY_WORDS * 64u) + owner;
+        const uint32_t slot = e & COOP_SLOT_MASK;        // the ray slot is the walking lane's; the candidate goes to the ray's owner
+        const float* rs = L.ray + ((e >> COOP_PAR_SHIFT) & 1u) * (COOP_RAY_WORDS * 64u) + (e >> COOP_LANE_SHIFT);
         const f3 ro = mk3(rs[0 * 64], rs[1 * 64], rs[2 * 64]);
         const f3 rd = mk3(rs[3 * 64], rs[4 * 64], rs[5 * 64]);
         float t, b1, b2;
         if (coop_triangle(A, slot, ro, rd, tmin, tmax, t, b1, b2)) {
-            const uint32_t low = (__float_as_uint(rs[6 * 64]) << COOP_INST_SHIFT) | (slot - __float_as_uint(rs[7 * 64]));
+            const uint32_t w6 = __float_as_uint(rs[6 * 64]);
+            const uint32_t inst = w6 & ((1u << COOP_OWNER_SHIFT) - 1u);
+            const uint32_t low = (inst << COOP_INST_SHIFT) | (slot - A.insts[inst]._p0);      // BLAS-local triangle slot
             const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;
-            atomicMin(&L.best[owner], key);
+            atomicMin(&L.best[w6 >> COOP_OWNER_SHIFT], key);
         }
     }
     qHead += n;
 }
 
 // append `cnt` (0..8) consecutive triangle slots starting at `start` for every lane; wave-uniform control
-__device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t tagBits, uint32_t cnt,
-                                             uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
+__device__ __forceinline__ void coop_enqueue_part(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t tagBits, uint32_t cnt,
+                                                  uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
 {
     uint32_t pre = 0, total = 0;
 #pragma unroll
@@ -123,6 +159,15 @@ __device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& 
     const uint32_t at = qTail + pre;
     for (uint32_t k = 0; k < cnt; ++k) L.queue[(at + k) & (COOP_QCAP - 1u)] = tagBits | (start + k);
     qTail += total;
+}
+
+__device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t tagBits, uint32_t cnt,
+                                             uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
+{
+    if (COOP_QCAP >= 512u) { coop_enqueue_part(A, L, lane, tagBits, cnt, start, qHead, qTail, tmin, tmax); return; }
+    // a smaller ring may not hold 64 x 8 entries: lanes 0-31 first, then lanes 32-63 (<= 256 entries each)
+    coop_enqueue_part(A, L, lane, tagBits, lane < 32u ? cnt : 0u, start, qHead, qTail, tmin, tmax);
+    coop_enqueue_part(A, L, lane, tagBits, lane < 32u ? 0u : cnt, start, qHead, qTail, tmin, tmax);
 }
 
 // Conservative world-space rejection of an instance whose BLAS root is an inner node.  The reference
@@ -170,6 +215,12 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     L.queue = lds + need * 64u;
     L.ray = reinterpret_cast<float*>(L.queue + COOP_QCAP);
     L.best = reinterpret_cast<unsigned long long*>(L.ray + 2u * COOP_RAY_WORDS * 64u);
+    L.pend = reinterpret_cast<uint32_t*>(L.best + 64);
+    L.pend[lane] = 0u;
+    // small launches are spread over the whole grid: a wave is handed at most `quota` rays per refill and its
+    // other lanes help (steal step); launches with >= 64 rays per resident wave run as before until the tail
+    const uint32_t nWavesGrid = gridDim.x * (blockDim.x >> 6);
+    const uint32_t quota = COOP_STEAL ? min(64u, max((uint32_t)COOP_MIN_QUOTA, (n + nWavesGrid - 1u) / nWavesGrid)) : 64u;
 
     uint32_t qHead = 0, qTail = 0;                         // wave-uniform, monotonically increasing
     bool exhausted = false;                                // wave-uniform: the global counter ran past n
@@ -177,13 +228,14 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     uint32_t rayIdx = COOP_NONE;                           // ray being walked (COOP_NONE: lane is free)
     uint32_t cur = COOP_NONE, sp = 0;
     uint32_t par = 0;                                      // LDS ray slot of the current instance
+    uint32_t owner = lane;                                 // lane whose ray is being walked: this one, or the lane it helps
+    uint32_t spInst = 0;                                   // inside a BLAS: stack[0, spInst) are top-level entries
     uint32_t markPrev = 0;                                 // qTail when the previous instance was left
     uint32_t finMark = 0; bool finishing = false;
     bool anyHit = (REC == 2);                              // this lane's ray ends at its first accepted candidate
     bool needShade = false;                                // the lane's item waits for a shade step
     typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
-    f3 rcpW = mk3(0.f, 0.f, 0.f); bool preOK = false; float oMax = 0.f;   // world-space pre-test state
     RayInst R;
     R.o = o; R.d = d; R.rcp = mk3(0.f, 0.f, 0.f); R.exactOnly = true;
 
@@ -191,12 +243,17 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
 
     for (;;) {
         // ---- lanes whose walk has ended wait for their queued tests, then hand the result over ----
-        if (rayIdx != COOP_NONE && cur == COOP_NONE && !finishing && !needShade) { finishing = true; finMark = qTail; }
+        // (a helper's walk ends like a ray's; an owner additionally waits until its helpers are back)
+        const bool stealPhase = COOP_STEAL && (exhausted || quota < 64u);
+        if (cur == COOP_NONE && !finishing && !needShade &&
+            (owner != lane || (rayIdx != COOP_NONE && (!stealPhase || *(volatile uint32_t*)&L.pend[lane] == 0u)))) { finishing = true; finMark = qTail; }
         const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
-        const bool isFree = (rayIdx == COOP_NONE);
+        const bool isFree = (rayIdx == COOP_NONE) && (owner == lane);
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
         const unsigned long long workMask = __ballot(cur != COOP_NONE);
-        const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
+        // free lanes count as idle while new rays can still be had -- in the steal phase only once the wave has
+        // run out of work altogether (otherwise they help)
+        const int nIdle = __popcll(doneMask) + ((!exhausted && (!stealPhase || workMask == 0ull)) ? __popcll(freeMask) : 0);
         const int nShade = Policy::kShades ? __popcll(__ballot(needShade)) : 0;
         // Step selection is greedy: of the step kinds that lanes are waiting for (refill, shade, top-level
         // node, instance entry, BLAS node) the wave takes the one with the most lanes, so every step runs
@@ -212,17 +269,15 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         // (re)start the walk of the ray now in o, d
 #define COOP_START_RAY(WALK) do {                                                                      \
             L.best[lane] = ~0ull;                                                                      \
-            sp = 0; par = 0; markPrev = qHead; finishing = false; needShade = false;                   \
+            sp = 0; spInst = 0; par = 0; markPrev = qHead; finishing = false; needShade = false;       \
             cur = (WALK) ? (TAG_TLAS | 0u) : COOP_NONE;                                                \
-            rcpW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                                            \
-            const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));                      \
-            const float amax_ = fmaxf(fmaxf(fabsf(rcpW.x), fabsf(rcpW.y)), fabsf(rcpW.z));             \
-            oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));                                   \
-            preOK = (amin_ > 1e-20f) && (amax_ < 1e20f) && (oMax < 1e20f);                             \
         } while (0)
 
-        if (nIdle > 0 && (nIdle >= nMaxWork + COOP_IDLE_BIAS || (workMask == 0ull && nShade == 0))) {
-            if (done) {
+        if (nIdle > 0 && ((stealPhase ? nIdle >= min(nMaxWork, COOP_TAIL_MIN) : nIdle >= nMaxWork + COOP_IDLE_BIAS) || (workMask == 0ull && nShade == 0))) {
+            if (done && owner != lane) {           // a helper is back: its subtree is walked and its queued tests are consumed
+                atomicSub(&L.pend[owner], 1u);
+                owner = lane; finishing = false;
+            } else if (done) {
                 Best B;
                 B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
                 const unsigned long long key = L.best[lane];
@@ -249,16 +304,17 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 else { anyHit = (REC == 2) || (REC == 3 && ah); COOP_START_RAY(true); }
             }
             if (!exhausted) {
-                const bool want = (rayIdx == COOP_NONE);
+                const bool want = (rayIdx == COOP_NONE) && (owner == lane);
                 const unsigned long long wm = __ballot(want);
-                const uint32_t cnt = (uint32_t)__popcll(wm);
+                const uint32_t cnt = min((uint32_t)__popcll(wm), quota);
                 if (cnt) {
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(counter, cnt);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base + cnt >= n) exhausted = true;
-                    if (want) {
-                        const uint32_t idx = base + lanes_below(wm);
+                    const uint32_t rank = lanes_below(wm);
+                    if (want && rank < cnt) {
+                        const uint32_t idx = base + rank;
                         if (idx < n) {
                             rayIdx = idx;
                             bool ah = false;
@@ -284,8 +340,60 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         }
         if (workMask == 0ull) {
             if (qTail != qHead) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
-            if (__ballot(rayIdx != COOP_NONE) == 0ull) break;      // exhausted, every lane free, queue empty
+            if (__ballot(rayIdx != COOP_NONE || owner != lane) == 0ull) break;      // exhausted, every lane free, queue empty
             continue;                                              // lanes still finishing: next round hands them over
+        }
+        // ---- steal step: free lanes take the bottom stack entry (largest pending subtree) of busy lanes ------
+        if (stealPhase) {
+            const bool canSteal = isFree;
+            const bool donor = has && sp > 0 && !(isInst && (cur & COOP_RESUME));   // (a resuming helper's stack entry has no instance yet)
+            const unsigned long long sMask = __ballot(canSteal), dMask = __ballot(donor);
+            const int pairs = min(__popcll(sMask), __popcll(dMask));
+            if (pairs > 0 && pairs >= min(COOP_STEAL_MIN, max(1, __popcll(workMask) >> 2))) {
+                // the donors' lane numbers go through the 64 ring slots behind the queue tail
+                if (qTail - qHead + 64u > COOP_QCAP) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
+                const uint32_t dRank = lanes_below(dMask), sRank = lanes_below(sMask);
+                uint32_t entry = COOP_NONE;
+                if (donor && dRank < (uint32_t)pairs) {
+                    L.queue[(qTail + dRank) & (COOP_QCAP - 1u)] = lane;
+                    // stack = [top-level entries | entries of the current BLAS]; visiting order is free, so the hole
+                    // is filled by moving the last entry of each segment down
+                    const bool inBlas = (tag == TAG_BLAS || tag == TAG_LEAF);
+                    const uint32_t split = inBlas ? spInst : sp;
+                    entry = L.stack[0];
+                    if (split > 0) {
+                        L.stack[0] = L.stack[(split - 1u) * 64u];
+                        if (sp > split) L.stack[(split - 1u) * 64u] = L.stack[(sp - 1u) * 64u];
+                        if (inBlas) spInst = split - 1u;
+                    } else {
+                        L.stack[0] = L.stack[(sp - 1u) * 64u];
+                    }
+                    --sp;
+                }
+                // the k-th stealer is served by the k-th donor.  Every lane shuffles (the others from themselves), so the
+                // donor's world ray lands directly in the stealer's registers
+                const bool takes = canSteal && sRank < (uint32_t)pairs;
+                const uint32_t src = takes ? (L.queue[(qTail + sRank) & (COOP_QCAP - 1u)] & 63u) : lane;
+                o.x = __shfl(o.x, src); o.y = __shfl(o.y, src); o.z = __shfl(o.z, src);
+                d.x = __shfl(d.x, src); d.y = __shfl(d.y, src); d.z = __shfl(d.z, src);
+                owner = __shfl(owner, src);
+                anyHit = __shfl((int)anyHit, src) != 0;
+                const uint32_t e2 = __shfl(entry, src), pd = __shfl(par, src);
+                if (takes) {
+                    cur = e2; sp = 0; spInst = 0; finishing = false;
+                    // a stolen BLAS entry belongs to the donor's current instance: re-enter that instance through the
+                    // ordinary instance step (same matrix, same world ray => the very same object-space ray), which
+                    // then continues with the stolen entry instead of the BLAS root
+                    const uint32_t t2 = e2 & TAG_MASK;
+                    if (t2 == TAG_BLAS || t2 == TAG_LEAF) {
+                        const uint32_t w6 = __float_as_uint(L.ray[pd * (COOP_RAY_WORDS * 64u) + 6u * 64u + src]);
+                        L.stack[0] = e2; sp = 1;
+                        cur = TAG_INST | COOP_RESUME | (w6 & COOP_IFIRST_MASK);
+                    }
+                    atomicAdd(&L.pend[owner], 1u);
+                }
+                continue;
+            }
         }
 
         // ---- queued piece of an oversized leaf, or a leaf root ----------------------------------------
@@ -308,9 +416,19 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                     const uint32_t count = w.x & 0x7fffffffu;
                     if (w.z == TYPE_INST) {
                         // every instance of the leaf is entered by the reference (no per-instance box test);
-                        // instances whose root box the ray provably misses are dropped here (coop_inst_pretest)
-                        for (uint32_t i = count; i-- > 0;)
-                            if (coop_inst_pretest(A.insts[w.y + i], o, rcpW, oMax, preOK)) { L.stack[sp * 64u] = TAG_INST | (w.y + i); ++sp; }
+                        // instances whose root box the ray provably misses are dropped here (coop_inst_pretest);
+                        // its per-ray constants are rebuilt here rather than kept in registers across the walk
+                        const f3 rcpW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+                        const float amax_ = fmaxf(fmaxf(fabsf(rcpW.x), fabsf(rcpW.y)), fabsf(rcpW.z));
+                        const float oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+                        const bool preOK = (amin_ > 1e-20f) && (amax_ < 1e20f) && (oMax < 1e20f);
+                        for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
+                            uint32_t m16 = 0;
+                            for (uint32_t i = 0; i < min(16u, count - b0); ++i)
+                                if (coop_inst_pretest(A.insts[w.y + b0 + i], o, rcpW, oMax, preOK)) m16 |= 1u << i;
+                            if (m16) { L.stack[sp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++sp; }
+                        }
                     }
                     COOP_POP();
                 }
@@ -323,9 +441,15 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             // every queued test of it lies before markPrev
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
             if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
-            if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+            if (REC != 1) { if (anyHit && ready && L.best[owner] != ~0ull) { cur = COOP_NONE; sp = 0; } }
             if (ready && cur != COOP_NONE) {
-                const uint32_t ci = cur & IDX_MASK;
+                const bool resume = COOP_STEAL && (cur & COOP_RESUME);
+                uint32_t ci = cur & COOP_IFIRST_MASK;
+                if (!resume) {               // lowest instance of the mask; the rest of the entry goes back on the stack
+                    const uint32_t m16 = (cur >> COOP_IMASK_SHIFT) & 0xffffu, rest = m16 & (m16 - 1u);
+                    ci += (uint32_t)__ffs((int)m16) - 1u;
+                    if (rest) { L.stack[sp * 64u] = TAG_INST | (rest << COOP_IMASK_SHIFT) | (cur & COOP_IFIRST_MASK); ++sp; }
+                }
                 const float4* ip = reinterpret_cast<const float4*>(A.insts + ci);
                 float m[16];
                 *reinterpret_cast<float4*>(m + 0) = ip[0];
@@ -344,8 +468,10 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 float* rs = L.ray + par * (COOP_RAY_WORDS * 64u) + lane;
                 rs[0 * 64] = R.o.x; rs[1 * 64] = R.o.y; rs[2 * 64] = R.o.z;
                 rs[3 * 64] = R.d.x; rs[4 * 64] = R.d.y; rs[5 * 64] = R.d.z;
-                rs[6 * 64] = __uint_as_float(ci); rs[7 * 64] = __uint_as_float(rdsc.z);
-                if (rdsc.y & WIDE_LEAF) {
+                rs[6 * 64] = __uint_as_float(ci | (owner << COOP_OWNER_SHIFT));
+                spInst = sp;                 // everything on the stack now is a top-level entry
+                if (resume) { spInst = sp - 1u; COOP_POP(); }
+                else if (rdsc.y & WIDE_LEAF) {
                     uint32_t cnt = rdsc.y & 0x7fffffffu, st = rdsc.x;
                     while (cnt > 8u) { L.stack[sp * 64u] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }
                     if (cnt) cur = leaf_item(st, cnt); else COOP_POP();
@@ -386,7 +512,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             coop_enqueue(A, L, lane, tagBits, cntR, stR, qHead, qTail, tmin, tmax);
             if (qTail - qHead >= 64u) {
                 coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
-                if (REC != 1) { if (anyHit && cur != COOP_NONE && L.best[lane] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+                if (REC != 1) { if (anyHit && cur != COOP_NONE && L.best[owner] != ~0ull) { cur = COOP_NONE; sp = 0; } }
             }
             continue;
         }
