@@ -11,6 +11,7 @@ namespace rdx {
 
 struct AccelView {                 // derived traversal layout (see rdx_types.h)
     const DNode* tnodes;
+    const DNode* ctnodes;          // the same nodes with the children ordered for the cooperative kernel (smaller stack need first)
     const DInst* insts;
     const DNode* bnodes;
     const DTri*  tris;

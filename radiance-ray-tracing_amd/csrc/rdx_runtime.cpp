@@ -31,7 +31,7 @@ using namespace rdx;
 // ------------------------------------------------------------------------------------------------
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
-    DNode* tnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
+    DNode* tnodes = nullptr; DNode* ctnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
     DWide* wide = nullptr;
     uint32_t stackNeed = 1;            // per-lane kernels (reference order: left child followed, right child pushed)
     uint32_t coopNeed = 1;             // wave-cooperative kernel (leaf children are never pushed, smaller subtree first)
@@ -39,11 +39,12 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     void release()
     {
         if (tnodes) HIP_IGN(hipFree(tnodes));
+        if (ctnodes) HIP_IGN(hipFree(ctnodes));
         if (insts) HIP_IGN(hipFree(insts));
         if (bnodes) HIP_IGN(hipFree(bnodes));
         if (tris) HIP_IGN(hipFree(tris));
         if (wide) HIP_IGN(hipFree(wide));
-        tnodes = nullptr; insts = nullptr; bnodes = nullptr; tris = nullptr; wide = nullptr;
+        tnodes = nullptr; ctnodes = nullptr; insts = nullptr; bnodes = nullptr; tris = nullptr; wide = nullptr;
     }
 };
 
@@ -309,6 +310,7 @@ int derive_accel(rdx_buffer_s* tb)
     // (cooperative kernel: the instances of a top-level leaf are pushed as 16-bit masks, one entry per 16 instances,
     //  and the entry being consumed is pushed back while one of its instances is walked)
     std::vector<uint32_t> needT(nTop, 0), needC(nTop, 0);
+    std::vector<DNode> dTc(dT);
     for (uint32_t i = nTop; i-- > 0;) {
         const BlobNode& n = tnodes[i];
         if (n.w0 & LEAF_BIT) {
@@ -322,7 +324,9 @@ int derive_accel(rdx_buffer_s* tb)
             needC[i] = (cnt + 15u) / 16u + mxc;
         } else {
             needT[i] = std::max(1u + needT[n.w0], needT[n.w1]);   // children have larger indices (DFS pre-order)
-            needC[i] = std::max(1u + needC[n.w0], needC[n.w1]);
+            // cooperative kernel: its own copy of the top-level nodes with the smaller-need child in the followed slot
+            if (needC[n.w1] < needC[n.w0]) std::swap(dTc[i].w0, dTc[i].w1);
+            needC[i] = std::max(1u + needC[dTc[i].w0], needC[dTc[i].w1]);
         }
     }
     auto ac = std::make_unique<AccelCache>();
@@ -338,6 +342,7 @@ int derive_accel(rdx_buffer_s* tb)
         return vec.empty() ? hipSuccess : hipMemcpy(dptr, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice);
     };
     HIP_OK(up(ac->tnodes, dT));
+    HIP_OK(up(ac->ctnodes, dTc));
     HIP_OK(up(ac->insts, dI));
     HIP_OK(up(ac->bnodes, dB));
     HIP_OK(up(ac->tris, dTri));
@@ -355,7 +360,7 @@ int derive_accel(rdx_buffer_s* tb)
 AccelView view_of(const rdx_buffer_s* tb)
 {
     AccelView v{};
-    v.tnodes = tb->accel->tnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
+    v.tnodes = tb->accel->tnodes; v.ctnodes = tb->accel->ctnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
     v.wide = tb->accel->wide;
     v.kernel = (g.kernel == 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
     v.stackNeed = tb->accel->stackNeed;

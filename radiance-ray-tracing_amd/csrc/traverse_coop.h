@@ -53,15 +53,16 @@
 namespace rdx {
 
 #ifndef COOP_QCAP
-#define COOP_QCAP 512u                 // queue ring capacity in entries (power of two, >= 256)
+#define COOP_QCAP 512u                 // queue ring capacity in entries: a power of two, and one enqueue (64 lanes x 8) must fit
 #endif
+static_assert(COOP_QCAP >= 512u && (COOP_QCAP & (COOP_QCAP - 1u)) == 0u, "queue ring too small for one enqueue");
 #define COOP_LANE_SHIFT 26u            // queue entry = owner lane << 26 | ray-slot bit << 25 | absolute triangle slot
 #define COOP_PAR_SHIFT 25u
 #define COOP_SLOT_MASK ((1u << 25) - 1u)
 #define COOP_INST_SHIFT 22u            // key low word = instance slot << 22 | BLAS-local triangle slot
 #define COOP_LOCAL_MASK ((1u << 22) - 1u)
 #define COOP_NONE 0xffffffffu
-#define COOP_RAY_WORDS 7u              // per lane per slot: o.xyz d.xyz (object space), instance slot | owner lane << 16
+#define COOP_RAY_WORDS 7u              // per lane: o.xyz d.xyz (object space), instance slot | owner lane << 16 of the instance being left
 #ifndef COOP_IDLE_BIAS
 #define COOP_IDLE_BIAS 16              // a refill step needs this many more idle lanes than the busiest work kind has (tuned: profiles/)
 #endif
@@ -86,7 +87,7 @@ namespace rdx {
 #define COOP_IMASK_SHIFT 13u
 #define COOP_IFIRST_MASK ((1u << COOP_IMASK_SHIFT) - 1u)
 
-__host__ __device__ inline uint32_t coop_words_per_wave(uint32_t need) { return need * 64u + COOP_QCAP + 2u * COOP_RAY_WORDS * 64u + 128u + 64u; }
+__host__ __device__ inline uint32_t coop_words_per_wave(uint32_t need) { return need * 64u + COOP_QCAP + COOP_RAY_WORDS * 64u + 128u + 64u; }
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
 {
@@ -96,7 +97,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
 struct CoopLds {
     uint32_t* stack;                 // [need][64]   (already offset by the lane)
     uint32_t* queue;                 // [COOP_QCAP]
-    float* ray;                      // [2 slots][8 words][64 lanes]
+    float* ray;                      // [7 words][64 lanes]: the object-space ray of the instance a lane has just left
     unsigned long long* best;        // [64]
     uint32_t* pend;                  // [64] helpers still walking for the ray owned by this lane
 };
@@ -120,32 +121,43 @@ __device__ __forceinline__ bool coop_triangle(const AccelView& A, uint32_t slot,
     return (det != 0) & !(b1 < 0 || b1 > 1) & !(b2 < 0 || b1 + b2 > 1) & (t > 0) & (t > tmin) & (t < tmax);
 }
 
-// one test step: up to 64 queued (owner ray slot, triangle) pairs, one per lane
+// one test step: up to 64 queued (walking lane, triangle) pairs, one per lane.  The object-space ray of an entry is
+// the walking lane's CURRENT one -- fetched from its registers by lane shuffles -- unless that lane has meanwhile
+// entered its next instance (the entry's parity bit differs from the lane's): then it is the ray parked in the
+// lane's LDS slot.  All 64 lanes must call this (the shuffles read the registers of active lanes).
 __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t& qHead,
-                                               uint32_t qTail, float tmin, float tmax)
+                                               uint32_t qTail, float tmin, float tmax, const RayInst& R, uint32_t par, uint32_t w6)
 {
     const uint32_t n = min(64u, qTail - qHead);
+    const uint32_t e = lane < n ? L.queue[(qHead + lane) & (COOP_QCAP - 1u)] : (lane << COOP_LANE_SHIFT);
+    const uint32_t wl = e >> COOP_LANE_SHIFT;
+    const uint32_t cpar = __shfl(par, wl);
+    uint32_t w = __shfl(w6, wl);
+    f3 ro = mk3(__shfl(R.o.x, wl), __shfl(R.o.y, wl), __shfl(R.o.z, wl));
+    f3 rd = mk3(__shfl(R.d.x, wl), __shfl(R.d.y, wl), __shfl(R.d.z, wl));
     if (lane < n) {
-        const uint32_t e = L.queue[(qHead + lane) & (COOP_QCAP - 1u)];
-        const uint32_t slot = e & COOP_SLOT_MASK;        // the ray slot is the walking lane's; the candidate goes to the ray's owner
-        const float* rs = L.ray + ((e >> COOP_PAR_SHIFT) & 1u) * (COOP_RAY_WORDS * 64u) + (e >> COOP_LANE_SHIFT);
-        const f3 ro = mk3(rs[0 * 64], rs[1 * 64], rs[2 * 64]);
-        const f3 rd = mk3(rs[3 * 64], rs[4 * 64], rs[5 * 64]);
+        const uint32_t slot = e & COOP_SLOT_MASK;
+        if (((e >> COOP_PAR_SHIFT) & 1u) != cpar) {
+            const float* rs = L.ray + wl;
+            ro = mk3(rs[0 * 64], rs[1 * 64], rs[2 * 64]);
+            rd = mk3(rs[3 * 64], rs[4 * 64], rs[5 * 64]);
+            w = __float_as_uint(rs[6 * 64]);
+        }
         float t, b1, b2;
         if (coop_triangle(A, slot, ro, rd, tmin, tmax, t, b1, b2)) {
-            const uint32_t w6 = __float_as_uint(rs[6 * 64]);
-            const uint32_t inst = w6 & ((1u << COOP_OWNER_SHIFT) - 1u);
+            const uint32_t inst = w & ((1u << COOP_OWNER_SHIFT) - 1u);
             const uint32_t low = (inst << COOP_INST_SHIFT) | (slot - A.insts[inst]._p0);      // BLAS-local triangle slot
             const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;
-            atomicMin(&L.best[w6 >> COOP_OWNER_SHIFT], key);
+            atomicMin(&L.best[w >> COOP_OWNER_SHIFT], key);   // the candidate goes to the ray's owner
         }
     }
     qHead += n;
 }
 
 // append `cnt` (0..8) consecutive triangle slots starting at `start` for every lane; wave-uniform control
-__device__ __forceinline__ void coop_enqueue_part(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t tagBits, uint32_t cnt,
-                                                  uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
+__device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t tagBits, uint32_t cnt,
+                                             uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax,
+                                             const RayInst& R, uint32_t par, uint32_t w6)
 {
     uint32_t pre = 0, total = 0;
 #pragma unroll
@@ -155,19 +167,10 @@ __device__ __forceinline__ void coop_enqueue_part(const AccelView& A, const Coop
         total += (uint32_t)__popcll(m) << b;
     }
     if (total == 0) return;
-    while (qTail - qHead + total > COOP_QCAP) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
+    while (qTail - qHead + total > COOP_QCAP) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     const uint32_t at = qTail + pre;
     for (uint32_t k = 0; k < cnt; ++k) L.queue[(at + k) & (COOP_QCAP - 1u)] = tagBits | (start + k);
     qTail += total;
-}
-
-__device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& L, uint32_t lane, uint32_t tagBits, uint32_t cnt,
-                                             uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
-{
-    if (COOP_QCAP >= 512u) { coop_enqueue_part(A, L, lane, tagBits, cnt, start, qHead, qTail, tmin, tmax); return; }
-    // a smaller ring may not hold 64 x 8 entries: lanes 0-31 first, then lanes 32-63 (<= 256 entries each)
-    coop_enqueue_part(A, L, lane, tagBits, lane < 32u ? cnt : 0u, start, qHead, qTail, tmin, tmax);
-    coop_enqueue_part(A, L, lane, tagBits, lane < 32u ? 0u : cnt, start, qHead, qTail, tmin, tmax);
 }
 
 // Conservative world-space rejection of an instance whose BLAS root is an inner node.  The reference
@@ -214,7 +217,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     L.stack = lds + lane;                                  // [level * 64]
     L.queue = lds + need * 64u;
     L.ray = reinterpret_cast<float*>(L.queue + COOP_QCAP);
-    L.best = reinterpret_cast<unsigned long long*>(L.ray + 2u * COOP_RAY_WORDS * 64u);
+    L.best = reinterpret_cast<unsigned long long*>(L.ray + COOP_RAY_WORDS * 64u);
     L.pend = reinterpret_cast<uint32_t*>(L.best + 64);
     L.pend[lane] = 0u;
     // small launches are spread over the whole grid: a wave is handed at most `quota` rays per refill and its
@@ -228,7 +231,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     uint32_t rayIdx = COOP_NONE;                           // ray being walked (COOP_NONE: lane is free)
     uint32_t cur = COOP_NONE, sp = 0;
     uint32_t par = 0;                                      // LDS ray slot of the current instance
-    uint32_t owner = lane;                                 // lane whose ray is being walked: this one, or the lane it helps
+    uint32_t w6 = lane << COOP_OWNER_SHIFT;                // instance slot being walked | << 16: the lane whose ray it is (this lane,
+                                                           // or the lane it helps)
+#define COOP_OWNER() (w6 >> COOP_OWNER_SHIFT)
     uint32_t spInst = 0;                                   // inside a BLAS: stack[0, spInst) are top-level entries
     uint32_t markPrev = 0;                                 // qTail when the previous instance was left
     uint32_t finMark = 0; bool finishing = false;
@@ -246,9 +251,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         // (a helper's walk ends like a ray's; an owner additionally waits until its helpers are back)
         const bool stealPhase = COOP_STEAL && (exhausted || quota < 64u);
         if (cur == COOP_NONE && !finishing && !needShade &&
-            (owner != lane || (rayIdx != COOP_NONE && (!stealPhase || *(volatile uint32_t*)&L.pend[lane] == 0u)))) { finishing = true; finMark = qTail; }
+            (COOP_OWNER() != lane || (rayIdx != COOP_NONE && (!stealPhase || *(volatile uint32_t*)&L.pend[lane] == 0u)))) { finishing = true; finMark = qTail; }
         const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
-        const bool isFree = (rayIdx == COOP_NONE) && (owner == lane);
+        const bool isFree = (rayIdx == COOP_NONE) && (COOP_OWNER() == lane);
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
         const unsigned long long workMask = __ballot(cur != COOP_NONE);
         // free lanes count as idle while new rays can still be had -- in the steal phase only once the wave has
@@ -274,9 +279,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         } while (0)
 
         if (nIdle > 0 && ((stealPhase ? nIdle >= min(nMaxWork, COOP_TAIL_MIN) : nIdle >= nMaxWork + COOP_IDLE_BIAS) || (workMask == 0ull && nShade == 0))) {
-            if (done && owner != lane) {           // a helper is back: its subtree is walked and its queued tests are consumed
-                atomicSub(&L.pend[owner], 1u);
-                owner = lane; finishing = false;
+            if (done && COOP_OWNER() != lane) {    // a helper is back: its subtree is walked and its queued tests are consumed
+                atomicSub(&L.pend[COOP_OWNER()], 1u);
+                w6 = lane << COOP_OWNER_SHIFT; finishing = false;
             } else if (done) {
                 Best B;
                 B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
@@ -304,7 +309,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 else { anyHit = (REC == 2) || (REC == 3 && ah); COOP_START_RAY(true); }
             }
             if (!exhausted) {
-                const bool want = (rayIdx == COOP_NONE) && (owner == lane);
+                const bool want = (rayIdx == COOP_NONE) && (COOP_OWNER() == lane);
                 const unsigned long long wm = __ballot(want);
                 const uint32_t cnt = min((uint32_t)__popcll(wm), quota);
                 if (cnt) {
@@ -339,8 +344,8 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             continue;
         }
         if (workMask == 0ull) {
-            if (qTail != qHead) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
-            if (__ballot(rayIdx != COOP_NONE || owner != lane) == 0ull) break;      // exhausted, every lane free, queue empty
+            if (qTail != qHead) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            if (__ballot(rayIdx != COOP_NONE || COOP_OWNER() != lane) == 0ull) break;      // exhausted, every lane free, queue empty
             continue;                                              // lanes still finishing: next round hands them over
         }
         // ---- steal step: free lanes take the bottom stack entry (largest pending subtree) of busy lanes ------
@@ -351,7 +356,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             const int pairs = min(__popcll(sMask), __popcll(dMask));
             if (pairs > 0 && pairs >= min(COOP_STEAL_MIN, max(1, __popcll(workMask) >> 2))) {
                 // the donors' lane numbers go through the 64 ring slots behind the queue tail
-                if (qTail - qHead + 64u > COOP_QCAP) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
+                if (qTail - qHead + 64u > COOP_QCAP) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
                 const uint32_t dRank = lanes_below(dMask), sRank = lanes_below(sMask);
                 uint32_t entry = COOP_NONE;
                 if (donor && dRank < (uint32_t)pairs) {
@@ -376,21 +381,21 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 const uint32_t src = takes ? (L.queue[(qTail + sRank) & (COOP_QCAP - 1u)] & 63u) : lane;
                 o.x = __shfl(o.x, src); o.y = __shfl(o.y, src); o.z = __shfl(o.z, src);
                 d.x = __shfl(d.x, src); d.y = __shfl(d.y, src); d.z = __shfl(d.z, src);
-                owner = __shfl(owner, src);
+                const uint32_t sw6 = __shfl(w6, src);           // donor: owner of the ray | the instance it is in
                 anyHit = __shfl((int)anyHit, src) != 0;
-                const uint32_t e2 = __shfl(entry, src), pd = __shfl(par, src);
+                const uint32_t e2 = __shfl(entry, src);
                 if (takes) {
                     cur = e2; sp = 0; spInst = 0; finishing = false;
+                    w6 = (sw6 & ~((1u << COOP_OWNER_SHIFT) - 1u)) | (w6 & ((1u << COOP_OWNER_SHIFT) - 1u));
                     // a stolen BLAS entry belongs to the donor's current instance: re-enter that instance through the
                     // ordinary instance step (same matrix, same world ray => the very same object-space ray), which
                     // then continues with the stolen entry instead of the BLAS root
                     const uint32_t t2 = e2 & TAG_MASK;
                     if (t2 == TAG_BLAS || t2 == TAG_LEAF) {
-                        const uint32_t w6 = __float_as_uint(L.ray[pd * (COOP_RAY_WORDS * 64u) + 6u * 64u + src]);
                         L.stack[0] = e2; sp = 1;
-                        cur = TAG_INST | COOP_RESUME | (w6 & COOP_IFIRST_MASK);
+                        cur = TAG_INST | COOP_RESUME | (sw6 & COOP_IFIRST_MASK);
                     }
-                    atomicAdd(&L.pend[owner], 1u);
+                    atomicAdd(&L.pend[COOP_OWNER()], 1u);
                 }
                 continue;
             }
@@ -400,13 +405,13 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         if (__any(isLeaf)) {
             uint32_t cnt = 0, st = 0;
             if (isLeaf) { st = cur & LEAF_START_MASK; cnt = ((cur >> LEAF_START_BITS) & 7u) + 1u; COOP_POP(); }
-            coop_enqueue(A, L, lane, (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT), cnt, st, qHead, qTail, tmin, tmax);
+            coop_enqueue(A, L, lane, (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT), cnt, st, qHead, qTail, tmin, tmax, R, par, w6);
             continue;
         }
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------
         if (nTop > 0 && nTop >= nNode && nTop >= nInst) {
             if (isTop) {
-                const float4* np = reinterpret_cast<const float4*>(A.tnodes + (cur & IDX_MASK));
+                const float4* np = reinterpret_cast<const float4*>(A.ctnodes + (cur & IDX_MASK));
                 const float4 bmin = np[0], bmax = np[1];
                 const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
                 if (!(w.x & LEAF_BIT)) {
@@ -440,8 +445,8 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             // the LDS ray slot about to be overwritten belongs to the instance before the previous one:
             // every queued test of it lies before markPrev
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
-            if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax); continue; }
-            if (REC != 1) { if (anyHit && ready && L.best[owner] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+            if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            if (REC != 1) { if (anyHit && ready && L.best[COOP_OWNER()] != ~0ull) { cur = COOP_NONE; sp = 0; } }
             if (ready && cur != COOP_NONE) {
                 const bool resume = COOP_STEAL && (cur & COOP_RESUME);
                 uint32_t ci = cur & COOP_IFIRST_MASK;
@@ -456,6 +461,13 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 *reinterpret_cast<float4*>(m + 4) = ip[1];
                 *reinterpret_cast<float4*>(m + 8) = ip[2];
                 *reinterpret_cast<float4*>(m + 12) = ip[3];
+                {   // park the ray of the instance being left: queued tests of it may still be pending
+                    float* rs = L.ray + lane;
+                    rs[0 * 64] = R.o.x; rs[1 * 64] = R.o.y; rs[2 * 64] = R.o.z;
+                    rs[3 * 64] = R.d.x; rs[4 * 64] = R.d.y; rs[5 * 64] = R.d.z;
+                    rs[6 * 64] = __uint_as_float(w6);
+                }
+                w6 = (w6 & ~((1u << COOP_OWNER_SHIFT) - 1u)) | ci;
                 R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
                 R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
                 R.rcp = mk3(1.0f / R.d.x, 1.0f / R.d.y, 1.0f / R.d.z);
@@ -465,10 +477,6 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
                 markPrev = qTail;            // everything queued so far belongs to instances being left
                 par ^= 1u;
-                float* rs = L.ray + par * (COOP_RAY_WORDS * 64u) + lane;
-                rs[0 * 64] = R.o.x; rs[1 * 64] = R.o.y; rs[2 * 64] = R.o.z;
-                rs[3 * 64] = R.d.x; rs[4 * 64] = R.d.y; rs[5 * 64] = R.d.z;
-                rs[6 * 64] = __uint_as_float(ci | (owner << COOP_OWNER_SHIFT));
                 spInst = sp;                 // everything on the stack now is a top-level entry
                 if (resume) { spInst = sp - 1u; COOP_POP(); }
                 else if (rdsc.y & WIDE_LEAF) {
@@ -508,18 +516,19 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 else COOP_POP();
             }
             const uint32_t tagBits = (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT);
-            coop_enqueue(A, L, lane, tagBits, cntL, stL, qHead, qTail, tmin, tmax);
-            coop_enqueue(A, L, lane, tagBits, cntR, stR, qHead, qTail, tmin, tmax);
+            coop_enqueue(A, L, lane, tagBits, cntL, stL, qHead, qTail, tmin, tmax, R, par, w6);
+            coop_enqueue(A, L, lane, tagBits, cntR, stR, qHead, qTail, tmin, tmax, R, par, w6);
             if (qTail - qHead >= 64u) {
-                coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
-                if (REC != 1) { if (anyHit && cur != COOP_NONE && L.best[owner] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+                coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
+                if (REC != 1) { if (anyHit && cur != COOP_NONE && L.best[COOP_OWNER()] != ~0ull) { cur = COOP_NONE; sp = 0; } }
             }
             continue;
         }
         // lanes are waiting below their thresholds and nothing else can run: let the queue advance
-        if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax);
+        if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     }
 #undef COOP_POP
+#undef COOP_OWNER
 #undef COOP_START_RAY
 }
 
