@@ -477,15 +477,24 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
             store_sample(ps, nPixels, sampleBase, frameID, slot, c);
         }
     }
-    // wave64 ballot compaction of the surviving paths into the B streams
+    // wave64 ballot compaction of the surviving paths into the B streams.  The output cursor is ONE device word:
+    // an atomic per wave (130 k of them on one address for a 1080p x 4 spp bounce) serialises in the L2 and was
+    // the whole cost of this kernel (1.5 ms whatever the shader did); the block's waves are therefore summed in
+    // LDS first and one lane per block moves the cursor.
+    __shared__ uint32_t s_cnt[RDX_BLOCK / 64], s_base;
     const unsigned long long m = __ballot(alive);
-    if (m == 0ull) return;
-    const uint32_t lane = __lane_id();
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(nOut, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < RDX_BLOCK / 64; ++w) tot += s_cnt[w];
+        s_base = tot ? atomicAdd(nOut, tot) : 0u;
+    }
+    __syncthreads();
     if (!alive) return;
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
     const uint32_t j = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
     const f3 lit = Cc + T * p.color;               // color += contribution * payload.color (shader.cl:240)
@@ -661,7 +670,8 @@ __device__ __forceinline__ void write_hit_record(const AccelView& A, const Trace
     static constexpr bool kShades = false;                                                                       \
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit, State&) const { return load(i, o, d, anyHit); } \
     __device__ __forceinline__ int finish(uint32_t i, const Best& b, f3& o, f3& d, bool&, State&) const { store(i, b, o, d); return COOP_RELEASE; } \
-    __device__ __forceinline__ int shade(uint32_t, f3&, f3&, bool&, State&) const { return COOP_RELEASE; }
+    __device__ __forceinline__ int shade(uint32_t, f3&, f3&, bool&, State&) const { return COOP_RELEASE; }            \
+    __device__ __forceinline__ void retire(State&) const {}
 
 struct ExtendPolicy {
     AccelView A; PathStreams ps;
@@ -766,7 +776,8 @@ struct PathPolicy {
     uint32_t nPixels, sampleBegin, totalSamples, maxDepth, sampleBase;
     f3 Ldir;
     unsigned long long* tally;        // [0] closest-hit rays, [1] shadow rays (= closest hits)
-    struct State { uint32_t pixel, frameID, depth, triSlot, inst; float t, b1, b2; };
+    struct State { uint32_t pixel, frameID, depth, triSlot, inst; float t, b1, b2;
+                   uint32_t nClosest, nShadow; };      // rays started by this lane (never reset by load): summed in retire()
     static constexpr bool kShades = true;
 
     __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit, State& st) const
@@ -779,8 +790,14 @@ struct PathPolicy {
         ps.thr[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(slot));
         ps.col[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         anyHit = false;
-        atomicAdd(tally + 0, 1ull);
+        st.nClosest++;
         return true;
+    }
+    __device__ __forceinline__ void retire(State& st) const      // one atomic per wave per tally, not one per ray
+    {
+        uint32_t a = st.nClosest, b = st.nShadow;
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+        if (__lane_id() == 0) { atomicAdd(tally + 0, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
     }
     __device__ __forceinline__ void end_path(uint32_t i, const State& st, f3 c) const
     {
@@ -795,7 +812,7 @@ struct PathPolicy {
         ps.thr[i] = make_float4(tn.x, tn.y, tn.z, ps.thr[i].w);
         st.depth++;
         o = mk3(no.x, no.y, no.z); d = mk3(nd.x, nd.y, nd.z); anyHit = false;
-        atomicAdd(tally + 0, 1ull);
+        st.nClosest++;
         return COOP_NEWRAY;
     }
     __device__ __forceinline__ int finish(uint32_t i, const Best& b, f3& o, f3& d, bool& anyHit, State& st) const
@@ -845,7 +862,7 @@ struct PathPolicy {
         ps.colLit[i] = make_float4(lit.x, lit.y, lit.z, 0.0f);
         ps.colSh[i] = make_float4(occ.x, occ.y, occ.z, 0.0f);
         o = p.shadowOrigin; d = Ldir; anyHit = true;   // traceRay(topLevel, 2, 4, hitPos, L, ...) (shader.cl:499-501)
-        atomicAdd(tally + 1, 1ull);
+        st.nShadow++;
         return COOP_NEWRAY;
     }
 };

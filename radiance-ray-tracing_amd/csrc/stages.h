@@ -87,21 +87,44 @@ __device__ inline float smith_lambda(f3 w, float a)   // pbr.cl:41-74 Lambda and
     return (sqrtf(1.0f + alpha2 * tan2) - 1.0f) / 2.0f;
 }
 
-// Tangent frame of a normal and its 4x4 inverse.  The reference rebuilds both inside every G_pbrt call
+// Tangent frame of a normal and its inverse.  The reference rebuilds both inside every G_pbrt call
 // and every sampled direction (pbr.cl:87-88, 309-311, 339-341, 362-364); for one hit they are the same
 // matrices, so they are built once here and reused -- same values, fewer instructions.
-struct NFrame { float tbn[16]; float inv[16]; };
+//
+// GetNormalSpace (math.cl:269-298) returns [T B N | 0; 0 0 0 1] and every use multiplies by a direction (w = 0),
+// so only the 3x3 block and the 3x3 block of the cofactor inverse (math.cl:56-183) are ever read.  With
+// m3 = m7 = m11 = m12 = m13 = m14 = 0 and m15 = 1 each of those cofactors keeps two of its six products (the
+// others are x*0*y = +-0, and a*1 = a), evaluated here in the reference's order: same values, the sign of an
+// exact zero aside.
+struct NFrame { float tbn[9]; float inv[9]; };      // row-major 3x3
 __device__ inline void make_frame(f3 n, NFrame& F)
 {
-    normal_space(n, F.tbn);
-    for (int i = 0; i < 16; ++i) F.inv[i] = 0.0f;      // reference: uninitialised if det == 0
-    inverse_mat4(F.tbn, F.inv);
+    float dd = 1.0f * n.x + 0.0f * n.y + 0.0f * n.z;
+    f3 t = mk3(0.0f, 1.0f, 0.0f);
+    if (1.0f - fabsf(dd) > 1e-6f) t = normalize3(cross3(mk3(1.0f, 0.0f, 0.0f), n));
+    const f3 b = cross3(n, t);
+    const float m0 = t.x, m1 = b.x, m2 = n.x, m4 = t.y, m5 = b.y, m6 = n.y, m8 = t.z, m9 = b.z, m10 = n.z;
+    F.tbn[0] = m0; F.tbn[1] = m1; F.tbn[2] = m2; F.tbn[3] = m4; F.tbn[4] = m5; F.tbn[5] = m6; F.tbn[6] = m8; F.tbn[7] = m9; F.tbn[8] = m10;
+    const float i0 = m5 * m10 - m9 * m6, i4 = -m4 * m10 + m8 * m6, i8 = m4 * m9 - m8 * m5;
+    const float i1 = -m1 * m10 + m9 * m2, i5 = m0 * m10 - m8 * m2, i9 = -m0 * m9 + m8 * m1;
+    const float i2 = m1 * m6 - m5 * m2, i6 = -m0 * m6 + m4 * m2, i10 = m0 * m5 - m4 * m1;
+    float det = m0 * i0 + m1 * i4 + m2 * i8;
+    for (int i = 0; i < 9; ++i) F.inv[i] = 0.0f;       // reference: uninitialised if det == 0
+    if (det == 0) return;
+    det = 1.0f / det;
+    F.inv[0] = i0 * det; F.inv[1] = i1 * det; F.inv[2] = i2 * det;
+    F.inv[3] = i4 * det; F.inv[4] = i5 * det; F.inv[5] = i6 * det;
+    F.inv[6] = i8 * det; F.inv[7] = i9 * det; F.inv[8] = i10 * det;
+}
+__device__ __forceinline__ f3 mat3_mul(const float* m, float x, float y, float z)
+{
+    return mk3(m[0] * x + m[1] * y + m[2] * z, m[3] * x + m[4] * y + m[5] * z, m[6] * x + m[7] * y + m[8] * z);
 }
 
 __device__ inline float g_pbrt(const NFrame& F, f3 wo, f3 wi, float roughness)   // pbr.cl:77-96
 {
-    f4 lo = mat4_mul(F.inv, wo.x, wo.y, wo.z, 0.0f);
-    f4 li = mat4_mul(F.inv, wi.x, wi.y, wi.z, 0.0f);
+    f3 lo = mat3_mul(F.inv, wo.x, wo.y, wo.z);
+    f3 li = mat3_mul(F.inv, wi.x, wi.y, wi.z);
     if (li.z < 0 || lo.z < 0) return 0.0f;
     return 1 / (1 + smith_lambda(mk3(li.x, li.y, li.z), roughness) + smith_lambda(mk3(lo.x, lo.y, lo.z), roughness));
 }
@@ -139,7 +162,7 @@ __device__ inline f3 microfacet_brdf(const NFrame& FN, f3 L, f3 V, f3 N, f3 albe
 __device__ inline f3 frame_dir(const NFrame& F, float theta, float phi)
 {
     float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
-    return mat4_mul3(F.tbn, st * cp, st * sp, ct, 0.0f);
+    return mat3_mul(F.tbn, st * cp, st * sp, ct);
 }
 
 // pbr.cl:289-385 sampleMicrofacetBRDF_transm.  The diffuse and the specular lobe share the frame of N,
@@ -203,7 +226,11 @@ __device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s
     const MeshInfo mi = s.meshInfo[h.instanceIndex];
     const Material mt = s.materials[mi.materialIndex];
     const uint32_t* ip = s.indexData + mi.indexOffset + h.primitiveIndex * 3;
+#ifdef RDX_EXP_SHADE_NOGATHER     // timing experiment (wrong results): no dependent index / normal gathers
+    const uint32_t i0 = 0, i1 = 1, i2 = 2;
+#else
     const uint32_t i0 = ip[0], i1 = ip[1], i2 = ip[2];
+#endif
 
     // interpolated vertex normal -> world by the object->world matrix, w = 0 (shader.cl:340-368)
     const float* nb = s.normalData + mi.normalOffset;
@@ -239,6 +266,11 @@ __device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s
     // deferred shadow query: traceRay(topLevel, 2, 4, hitPos, L, 0.001, 1000) (shader.cl:499-501)
     p.wantsShadowRay = true;
     p.shadowOrigin = hitPos;
+#ifdef RDX_EXP_SHADE_CHEAP        // timing experiment (wrong results): all loads, none of the BRDF arithmetic
+    p.color = albedo * (metallic + roughness + transmission + ior) + V + L; p.colorOccluded = albedo;
+    p.nextRayOrigin = hitPos; p.nextRayDirection = faceN; p.nextFactor = albedo;
+    return;
+#endif
     const float* lc = s.scene->lights[0].color;
     NFrame FN;
     make_frame(N, FN);

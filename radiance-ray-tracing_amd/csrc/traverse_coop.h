@@ -80,6 +80,9 @@ static_assert(COOP_QCAP >= 512u && (COOP_QCAP & (COOP_QCAP - 1u)) == 0u, "queue 
 #ifndef COOP_TAIL_MIN
 #define COOP_TAIL_MIN 4                // while stealing: finished lanes are handed over as soon as this many wait
 #endif
+#ifndef COOP_CHUNK_MAX
+#define COOP_CHUNK_MAX 512u            // most ray indices a wave reserves with one atomic on the global counter (64 = one per refill)
+#endif
 #define COOP_OWNER_SHIFT 16u           // ray slot word 6 = instance slot | owner lane << 16
 #define COOP_RESUME (1u << 29)         // TAG_INST work item of a helper: enter the instance, then continue with the stolen entry on the stack
 // TAG_INST work item = up to 16 instances of one top-level leaf: first instance slot (13 bits) | 16-bit mask of the
@@ -129,6 +132,9 @@ __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds
                                                uint32_t qTail, float tmin, float tmax, const RayInst& R, uint32_t par, uint32_t w6)
 {
     const uint32_t n = min(64u, qTail - qHead);
+#ifdef COOP_EXP_NOTEST            // timing experiment (results are wrong): consume the entries without testing them
+    qHead += n; return;
+#endif
     const uint32_t e = lane < n ? L.queue[(qHead + lane) & (COOP_QCAP - 1u)] : (lane << COOP_LANE_SHIFT);
     const uint32_t wl = e >> COOP_LANE_SHIFT;
     const uint32_t cpar = __shfl(par, wl);
@@ -159,6 +165,9 @@ __device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& 
                                              uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax,
                                              const RayInst& R, uint32_t par, uint32_t w6)
 {
+#ifdef COOP_EXP_NOENQ             // timing experiment (results are wrong): box traversal only
+    return;
+#endif
     uint32_t pre = 0, total = 0;
 #pragma unroll
     for (uint32_t b = 0; b < 4; ++b) {
@@ -169,6 +178,10 @@ __device__ __forceinline__ void coop_enqueue(const AccelView& A, const CoopLds& 
     if (total == 0) return;
     while (qTail - qHead + total > COOP_QCAP) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     const uint32_t at = qTail + pre;
+#ifdef COOP_EXP_NOWRITE           // timing experiment (results are wrong): prefix sums only, nothing queued
+    if (at == 0xffffffffu) qTail += total;
+    return;
+#endif
     for (uint32_t k = 0; k < cnt; ++k) L.queue[(at + k) & (COOP_QCAP - 1u)] = tagBits | (start + k);
     qTail += total;
 }
@@ -200,6 +213,7 @@ __device__ __forceinline__ bool coop_inst_pretest(const DInst& I, f3 o, f3 rcpW,
 //                                                       COOP_SHADE: wait for a shade step; COOP_NEWRAY: o, d, anyHit
 //                                                       now hold the item's next ray
 //   int  shade(i, o, d, anyHit, State&)                 converged shading step (COOP_RELEASE or COOP_NEWRAY)
+//   void retire(State&)                                 called once by every lane when the wave leaves
 // REC: 1 = every ray is a closest-hit ray, 2 = every ray is an any-hit (shadow) ray, 3 = per ray (policy).
 //
 // All 64 lanes of the wave call this; `counter` is a zero-initialised device word shared by the grid.
@@ -223,10 +237,16 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     // small launches are spread over the whole grid: a wave is handed at most `quota` rays per refill and its
     // other lanes help (steal step); launches with >= 64 rays per resident wave run as before until the tail
     const uint32_t nWavesGrid = gridDim.x * (blockDim.x >> 6);
+    // (camera rays -- REC 1 launches -- are taken 64 at a time: measured faster than chunks, tools/gpu_variants.sh)
+    const uint32_t chunkMax = (REC == 1) ? 64u : (uint32_t)COOP_CHUNK_MAX;
+    uint32_t chunk = min(chunkMax, max(64u, (n / (4u * nWavesGrid)) & ~63u));
     const uint32_t quota = COOP_STEAL ? min(64u, max((uint32_t)COOP_MIN_QUOTA, (n + nWavesGrid - 1u) / nWavesGrid)) : 64u;
 
     uint32_t qHead = 0, qTail = 0;                         // wave-uniform, monotonically increasing
-    bool exhausted = false;                                // wave-uniform: the global counter ran past n
+    bool exhausted = false;                                // wave-uniform: the global counter ran past n and the wave's own
+                                                           // reservation is used up
+    uint32_t resBase = 0, resEnd = 0;                      // wave-uniform: ray indices reserved by this wave, not yet handed out
+    bool lastOfAll = false;                                // this wave's reservation reached the end of the launch
     // per-lane ray state
     uint32_t rayIdx = COOP_NONE;                           // ray being walked (COOP_NONE: lane is free)
     uint32_t cur = COOP_NONE, sp = 0;
@@ -311,12 +331,26 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             if (!exhausted) {
                 const bool want = (rayIdx == COOP_NONE) && (COOP_OWNER() == lane);
                 const unsigned long long wm = __ballot(want);
-                const uint32_t cnt = min((uint32_t)__popcll(wm), quota);
+                uint32_t cnt = min((uint32_t)__popcll(wm), quota);
                 if (cnt) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(counter, cnt);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base + cnt >= n) exhausted = true;
+                    // Ray indices are reserved from the global counter in chunks and handed out from the wave's own
+                    // reservation: one atomic round trip per chunk instead of per refill.  Guided self-scheduling:
+                    // the chunk is 1/4 of an even share of what was left at the previous reservation, between 64
+                    // and COOP_CHUNK_MAX, so reservations shrink towards the end of the launch and no wave sits on
+                    // a large private backlog while others have run dry.
+                    if (resBase == resEnd) {
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(counter, chunk);
+                        b = __builtin_amdgcn_readfirstlane(b);
+                        resBase = min(b, n); resEnd = min(b + chunk, n);
+                        lastOfAll = (b + chunk >= n);
+                        const uint32_t left = n - resEnd;
+                        chunk = min(chunkMax, max(64u, (left / (4u * nWavesGrid)) & ~63u));
+                    }
+                    cnt = min(cnt, resEnd - resBase);
+                    const uint32_t base = resBase;
+                    resBase += cnt;
+                    if (resBase == resEnd && lastOfAll) exhausted = true;
                     const uint32_t rank = lanes_below(wm);
                     if (want && rank < cnt) {
                         const uint32_t idx = base + rank;
@@ -527,6 +561,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         // lanes are waiting below their thresholds and nothing else can run: let the queue advance
         if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     }
+    pol.retire(st);                      // all 64 lanes, converged: per-lane tallies of the policy
 #undef COOP_POP
 #undef COOP_OWNER
 #undef COOP_START_RAY

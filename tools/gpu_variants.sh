@@ -14,3 +14,8 @@ import json; d=json.load(open('gpurun_out/bv.json')); s=d['stage_ms_per_frame'];
   done
   [ -n "$SKIP_SCALE" ] || timeout -k 10 200 python tools/trav_scale.py c1_cornell 2>&1 | grep "kernel=2" | awk '{printf "%s %s; ", $2" "$3, $5}'; echo
 done
+unset RDX_LIB
+for wl in sample1 sponza; do
+timeout -k 10 200 python bench.py --steps 6 --warmup 2 --workload $wl --pipeline 1 --no-cpu-baseline > gpurun_out/bv.json 2>gpurun_out/bv.err && python -c "
+import json; d=json.load(open('gpurun_out/bv.json')); s=d['stage_ms_per_frame']; print('pipeline 1 $wl', d['value'], d['ms_per_step'], 'path', s['path'])"
+done
