@@ -441,11 +441,14 @@ __device__ __forceinline__ void fill_hit_info(const AccelView& A, uint32_t instS
 #ifndef RDX_SHADE_WAVES
 #define RDX_SHADE_WAVES 1
 #endif
-__global__ void __launch_bounds__(RDX_BLOCK, RDX_SHADE_WAVES)
+#ifndef RDX_SHADE_BLOCK
+#define RDX_SHADE_BLOCK 256
+#endif
+__global__ void __launch_bounds__(RDX_SHADE_BLOCK, RDX_SHADE_WAVES)
 k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ nOut,
         uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
 {
-    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    const uint32_t i = blockIdx.x * RDX_SHADE_BLOCK + threadIdx.x;
     const bool active = i < *nPtr;
     bool alive = false;
     Payload p;
@@ -481,14 +484,14 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
     // an atomic per wave (130 k of them on one address for a 1080p x 4 spp bounce) serialises in the L2 and was
     // the whole cost of this kernel (1.5 ms whatever the shader did); the block's waves are therefore summed in
     // LDS first and one lane per block moves the cursor.
-    __shared__ uint32_t s_cnt[RDX_BLOCK / 64], s_base;
+    __shared__ uint32_t s_cnt[RDX_SHADE_BLOCK / 64], s_base;
     const unsigned long long m = __ballot(alive);
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
-        for (uint32_t w = 0; w < RDX_BLOCK / 64; ++w) tot += s_cnt[w];
+        for (uint32_t w = 0; w < RDX_SHADE_BLOCK / 64; ++w) tot += s_cnt[w];
         s_base = tot ? atomicAdd(nOut, tot) : 0u;
     }
     __syncthreads();
@@ -1058,7 +1061,7 @@ void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
                   uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
 {
     if (!nMax) return;
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(nMax, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, av, sc, ps, nPtr, nOut, depth,
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(nMax, RDX_SHADE_BLOCK)), dim3(RDX_SHADE_BLOCK), 0, st, av, sc, ps, nPtr, nOut, depth,
                        maxDepth, nPixels, sampleBase);
 }
 
