@@ -436,3 +436,55 @@ def test_4k_chunked_frame(mods):
         assert np.array_equal(_bits(a), _bits(dev.read_scratch()))
     finally:
         rd.SetOption("chunk_paths", 16 << 20)
+
+
+def test_instanced_grid_and_ragged_batches(mods):
+    """45 instances of two shared BLASes (the 9-instance grid of samples/sample2.cpp:404-505, enlarged so that
+    top-level leaves and the cooperative kernel's instance-mask stack entries, subtree stealing and ray-index
+    reservation all see many instances): the wave-cooperative kernel, the per-lane wide kernel and the
+    reference-order kernel agree with the oracle bit for bit on ragged batch sizes -- 0, 1, 63, 64, 65, 1000 and
+    20 000 rays (less than one wave, exactly one, one and a bit, less than one ray per resident wave, many)"""
+    rd, scenes = mods
+    s = scenes.Scene("grid")
+    ball = s.add_mesh(scenes.icosphere(2, 0.45))
+    cube = s.add_mesh(scenes.box([-0.35, -0.35, -0.35], [0.35, 0.35, 0.35]))
+    s.materials = [scenes.material((0.7, 0.7, 0.7), 0.0, 0.5), scenes.material((0.9, 0.8, 0.5), 0.9, 0.2)]
+    k = 0
+    for ix in range(5):
+        for iy in range(3):
+            for iz in range(3):
+                tf = scenes.translate(1.3 * (ix - 2), 1.3 * (iy - 1), 1.3 * (iz - 1)) @ scenes.rotate_y(11.0 * k) @ \
+                    scenes.scale(1.0 + 0.05 * (k % 3), 1.0, 1.0 - 0.04 * (k % 2))
+                s.add_instance(ball if k % 2 == 0 else cube, tf, k % 2)
+                k += 1
+    s.camera = scenes.blender_camera(64, 48, 0.05, 0.036, 9.0, 0.0, (0.5, 9.0, 1.0), (-96.0, 180.0, 0.0))
+    s.sceneProps = scenes.blender_dir_light(-45.0, 20.0, 5.0)
+    s.rtprop = scenes._rtprop(0, 2, 4)
+    dev = scenes.DeviceScene(s)
+    blob_o, _, _ = ob.scene_tlas(s)
+    assert rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes() == blob_o
+    osc = ob.OracleScene(s, blob_o)
+    o, d = _ray_batch(osc, 5000, 11)
+    fields = ("distance", "primitiveIndex", "instanceIndex", "instanceCustomIndex", "barycentric", "hitPoint", "transform")
+    hits_total = 0
+    for n in (0, 1, 63, 64, 65, 1000, 20000):
+        for rec in (1, 2):
+            ref = ob.trace_batch(blob_o, o[:n], d[:n], 0.001, 1000.0, rec)
+            for kernel in (2, 1, 0):
+                rd.SetOption("kernel", kernel)
+                try:
+                    got = rd.TraceBatch(dev.topAccelStruct, o[:n], d[:n], 0.001, 1000.0, rec)
+                finally:
+                    rd.SetOption("kernel", 2)
+                assert got.shape[0] == n and np.array_equal(ref["hit"], got["hit"]), (n, rec, kernel)
+                h = ref["hit"] == 1
+                if rec == 1:
+                    for f in fields:
+                        assert np.array_equal(_bits(ref[f][h]), _bits(got[f][h])), (n, kernel, f)
+            hits_total += int(h.sum())
+    assert hits_total > 5000
+    # and a frame of it against the oracle (progressive: two TraceRays calls)
+    osc.frame(); osc.frame()
+    dev.render(); dev.set_rtprop(totalSamples=2); dev.render()
+    got = dev.read_scratch().reshape(-1).astype(np.float64)
+    assert np.sqrt(np.mean((got - osc.scratch.astype(np.float64)) ** 2)) < 1e-4
