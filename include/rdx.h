@@ -69,8 +69,36 @@ rdx_buffer  rdx_tlas_build(const rdx_instance* instances, uint32_t ninstances);
 void*       rdx_tlas_build_blob(const rdx_instance* instances, uint32_t ninstances, uint32_t* size_out,
                                 int* max_depth_out);
 void        rdx_free(void* p);
+/* The cache file is the raw blob, as the reference writes it; rdx_tlas_to_file also writes `<path>.meta` (magic,
+ * version, byte count, FNV-1a hash) and rdx_tlas_from_file refuses a blob that contradicts an existing side-car. */
 int         rdx_tlas_to_file(rdx_buffer tlas, const char* path);
 rdx_buffer  rdx_tlas_from_file(const char* path);
+
+/* ---- scene ingestion: replaces the assimp import of RD::Scene::Load (tools/sceneBuilder.cpp:27-258) for Wavefront
+ *      OBJ + MTL files: the concatenated vertex / index / uv / normal streams, one MeshInfo per mesh, the Material
+ *      table (core.h:122-158 layouts).  Host only, needs no GPU.  Every mesh is one instance (identity transform,
+ *      customInstanceID = materialIndex, sceneBuilder.cpp:287-315).  Arrays are malloc'ed; release with rdx_obj_free. */
+typedef struct rdx_material {        /* RD::Material, core.h:122-136 / pbr.cl:387-425 (48 B) */
+    float   albedo[4];
+    float   metallic, roughness, transmission, ior;
+    int32_t albedoTexIdx, metallicTexIdx, roughnessTexIdx, normalTexIdx;
+} rdx_material;
+typedef struct rdx_mesh_info {       /* RD::MeshInfo, core.h:138-148 (32 B); offsets in floats / indices */
+    int32_t vertexOffset, indexOffset, uvOffset, normalOffset, materialIndex, _0, _1, _2;
+} rdx_mesh_info;
+typedef struct rdx_obj_scene {
+    uint32_t nmeshes, nvertices, ntriangles, nmaterials;
+    rdx_mesh_info* meshInfo;          /* [nmeshes] */
+    float*    vertex;                 /* [nvertices][3] */
+    uint32_t* index;                  /* [ntriangles][3], mesh-local vertex numbers */
+    float*    uv;                     /* [nvertices][3] (u, v, 0) */
+    float*    normal;                 /* [nvertices][3] */
+    rdx_material* materials;          /* [nmaterials] */
+    uint32_t* meshVertexCount;        /* [nmeshes] */
+    uint32_t* meshTriangleCount;      /* [nmeshes] */
+} rdx_obj_scene;
+int         rdx_obj_load(const char* path, rdx_obj_scene* out);
+void        rdx_obj_free(rdx_obj_scene* scene);
 
 /* ---- pipeline: replaces CreateShaderModule / BindPipeline / BindDescriptorSet / TraceRays
  *      (radiance.h:130-144, radiance.cpp:152-179,226-267).

@@ -25,6 +25,24 @@ class rdx_trace_stats(C.Structure):
                 ("ms_fused", C.c_float), ("ms_path", C.c_float), ("launches_extend", C.c_uint32), ("launches_shadow", C.c_uint32)]
 
 
+class rdx_material(C.Structure):
+    _fields_ = [("albedo", C.c_float * 4), ("metallic", C.c_float), ("roughness", C.c_float), ("transmission", C.c_float),
+                ("ior", C.c_float), ("albedoTexIdx", C.c_int32), ("metallicTexIdx", C.c_int32), ("roughnessTexIdx", C.c_int32),
+                ("normalTexIdx", C.c_int32)]
+
+
+class rdx_mesh_info(C.Structure):
+    _fields_ = [("vertexOffset", C.c_int32), ("indexOffset", C.c_int32), ("uvOffset", C.c_int32), ("normalOffset", C.c_int32),
+                ("materialIndex", C.c_int32), ("_0", C.c_int32), ("_1", C.c_int32), ("_2", C.c_int32)]
+
+
+class rdx_obj_scene(C.Structure):
+    _fields_ = [("nmeshes", C.c_uint32), ("nvertices", C.c_uint32), ("ntriangles", C.c_uint32), ("nmaterials", C.c_uint32),
+                ("meshInfo", C.POINTER(rdx_mesh_info)), ("vertex", C.POINTER(C.c_float)), ("index", C.POINTER(C.c_uint32)),
+                ("uv", C.POINTER(C.c_float)), ("normal", C.POINTER(C.c_float)), ("materials", C.POINTER(rdx_material)),
+                ("meshVertexCount", C.POINTER(C.c_uint32)), ("meshTriangleCount", C.POINTER(C.c_uint32))]
+
+
 class rdx_hit(C.Structure):
     _fields_ = [("hitPoint", C.c_float * 3), ("distance", C.c_float), ("primitiveIndex", C.c_uint32),
                 ("instanceIndex", C.c_uint32), ("instanceCustomIndex", C.c_uint32),
@@ -75,6 +93,8 @@ SIGNATURES = {
     "rdx_material_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "rdx_generate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rdx_pcg3d_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "rdx_obj_load": (C.c_int, [C.c_char_p, C.POINTER(rdx_obj_scene)]),
+    "rdx_obj_free": (None, [C.POINTER(rdx_obj_scene)]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "librdx.so")
 EXTRA = os.environ.get("RDX_DEFINES", "").split()
 if os.environ.get("RDX_LIB_NAME"):
     LIB = os.path.join(HERE, os.environ["RDX_LIB_NAME"])
-SOURCES = ["kernels.hip", "rdx_runtime.cpp", "bvh_build.cpp"]
+SOURCES = ["kernels.hip", "rdx_runtime.cpp", "bvh_build.cpp", "scene_obj.cpp"]
 HEADERS = ["kernels.h", "stages.h", "device_math.h", "rdx_types.h", "bvh_build.h", "sbt_generated.h", "traverse_coop.h",
            os.path.join("..", "..", "include", "rdx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

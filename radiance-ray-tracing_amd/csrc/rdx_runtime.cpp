@@ -667,6 +667,46 @@ extern "C" rdx_buffer rdx_tlas_build(const rdx_instance* inst, uint32_t n)
 }
 
 // radiance.cpp:428-448: raw dump of the TLAS buffer, size from header word 3
+// error text set from the library's other translation units (scene_obj.cpp)
+namespace rdx { int fail_text(const char* text) { return fail("%s", text); } }
+
+// Side-car of a TLAS cache file: the cache itself stays the raw blob the reference writes
+// (radiance.cpp:428-448: totalBufferSize bytes, no header of its own), so files written by either side load on the
+// other; `<path>.meta` adds what the raw format cannot say -- a magic / version line, the byte count and an FNV-1a
+// hash of the blob.  FileToTopAccelStruct verifies a side-car when one exists and refuses a blob that does not
+// match it (a truncated or stale cache is otherwise only noticed as a wrong picture); a cache without side-car
+// loads as before.
+static uint64_t fnv1a64(const uint8_t* p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+static int write_cache_meta(const char* path, const std::vector<uint8_t>& data)
+{
+    const std::string mp = std::string(path) + ".meta";
+    FILE* fp = fopen(mp.c_str(), "w");
+    if (!fp) return fail("TopAccelStructToFile: cannot open '%s' for writing", mp.c_str());
+    const int ok = fprintf(fp, "RDXCACHE 1\nbytes %zu\nfnv1a64 %016llx\n", data.size(), (unsigned long long)fnv1a64(data.data(), data.size()));
+    fclose(fp);
+    return ok > 0 ? 0 : fail("TopAccelStructToFile: short write to '%s'", mp.c_str());
+}
+// 0 = no side-car or it matches, -1 = mismatch (error text set)
+static int check_cache_meta(const char* path, const std::vector<uint8_t>& data)
+{
+    const std::string mp = std::string(path) + ".meta";
+    FILE* fp = fopen(mp.c_str(), "r");
+    if (!fp) return 0;
+    char magic[16] = ""; int ver = 0; size_t bytes = 0; unsigned long long h = 0;
+    const int n = fscanf(fp, "%15s %d bytes %zu fnv1a64 %llx", magic, &ver, &bytes, &h);
+    fclose(fp);
+    if (n != 4 || strcmp(magic, "RDXCACHE")) return fail("FileToTopAccelStruct: '%s' is not a cache side-car", mp.c_str());
+    if (ver != 1) return fail("FileToTopAccelStruct: side-car '%s' has version %d, this library reads version 1", mp.c_str(), ver);
+    if (bytes != data.size()) return fail("FileToTopAccelStruct: '%s' holds %zu bytes, its side-car says %zu (stale or truncated cache)", path, data.size(), bytes);
+    if (h != fnv1a64(data.data(), data.size())) return fail("FileToTopAccelStruct: '%s' does not match the hash in its side-car (stale or corrupted cache)", path);
+    return 0;
+}
+
 extern "C" int rdx_tlas_to_file(rdx_buffer tlas, const char* path)
 {
     if (!tlas || !known_buffer(tlas)) return fail("TopAccelStructToFile: invalid handle");
@@ -679,7 +719,8 @@ extern "C" int rdx_tlas_to_file(rdx_buffer tlas, const char* path)
     if (!fp) return fail("TopAccelStructToFile: cannot open '%s' for writing", path);
     const size_t wr = fwrite(data.data(), 1, data.size(), fp);
     fclose(fp);
-    return wr == data.size() ? 0 : fail("TopAccelStructToFile: short write to '%s'", path);
+    if (wr != data.size()) return fail("TopAccelStructToFile: short write to '%s'", path);
+    return write_cache_meta(path, data);
 }
 
 // radiance.cpp:450-479
@@ -696,6 +737,7 @@ extern "C" rdx_buffer rdx_tlas_from_file(const char* path)
     const size_t rd = fread(data.data(), 1, data.size(), fp);
     fclose(fp);
     if (rd != data.size()) { fail("FileToTopAccelStruct: short read of '%s' (%zu of %zu bytes)", path, rd, data.size()); return nullptr; }
+    if (check_cache_meta(path, data)) return nullptr;
     return tlas_from_blob(std::move(data));
 }
 

@@ -23,6 +23,7 @@ Configs (BASELINE.json / SURVEY.md 8d):
     c4_atrium_10m     San-Miguel-scale: the same generator at 10.4 M unique triangles
 """
 import math
+import os
 
 import numpy as np
 
@@ -443,3 +444,74 @@ def c4_atrium_10m(width=1920, height=1080, spp=4, depth=8):
 
 
 CONFIGS = {"c0_two_boxes": c0_two_boxes, "c1_cornell": c1_cornell, "c2_atrium": c2_atrium, "c4_atrium_10m": c4_atrium_10m}
+
+
+# ---------------------------------------------------------------------------------------------------
+# Wavefront OBJ + MTL (scene ingestion without assimp; parser = rdx_obj_load in librdx.so)
+# ---------------------------------------------------------------------------------------------------
+def load_obj(path, width=1920, height=1080, spp=4, depth=8, camera=None, light=None):
+    """Scene from an OBJ (+ MTL) file: the buffers RD::Scene::Load (tools/sceneBuilder.cpp:27-258) would upload, one
+    instance per mesh with the identity transform.  `camera` / `light` default to a view of the scene's bounding box
+    from the front-top and the sample1 light (an OBJ file carries neither)."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    o = _lib.rdx_obj_scene()
+    if L.rdx_obj_load(os.fsencode(path), C.byref(o)):
+        raise rd.RadianceError(_lib.last_error())
+    try:
+        def arr(ptr, n, dt):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).view(dt).copy() if n else np.zeros(0, dt)
+        info = arr(C.cast(o.meshInfo, C.POINTER(C.c_int32)), o.nmeshes * 8, np.int32).view(rd.MeshInfo)
+        vertex = arr(o.vertex, o.nvertices * 3, F).reshape(-1, 3)
+        index = arr(o.index, o.ntriangles * 3, np.uint32).reshape(-1, 3)
+        uv = arr(o.uv, o.nvertices * 3, F).reshape(-1, 3)
+        normal = arr(o.normal, o.nvertices * 3, F).reshape(-1, 3)
+        mats = arr(C.cast(o.materials, C.POINTER(C.c_int32)), o.nmaterials * 12, np.int32).view(rd.Material)
+        vcount = arr(o.meshVertexCount, o.nmeshes, np.uint32)
+        tcount = arr(o.meshTriangleCount, o.nmeshes, np.uint32)
+    finally:
+        L.rdx_obj_free(C.byref(o))
+    s = Scene(os.path.basename(path))
+    s.materials = [mats[i] for i in range(mats.shape[0])]
+    for k in range(info.shape[0]):
+        v0, t0 = int(info[k]["vertexOffset"]) // 3, int(info[k]["indexOffset"]) // 3
+        nv, nt = int(vcount[k]), int(tcount[k])
+        m = s.add_mesh((vertex[v0:v0 + nv].copy(), index[t0:t0 + nt].copy(), normal[v0:v0 + nv].copy(), uv[v0:v0 + nv].copy()))
+        s.add_instance(m, None, int(info[k]["materialIndex"]))
+    lo, hi = vertex.min(0), vertex.max(0)
+    c, ext = (lo + hi) / 2, float(np.max(hi - lo))
+    s.camera = camera if camera is not None else blender_camera(
+        width, height, 0.050, 0.036, 2.0 * ext, 0.0, (float(c[0]), float(c[2]) + 2.0 * ext, float(c[1]) + 0.35 * ext), (-100.0, 180.0, 0.0))
+    s.sceneProps = light if light is not None else blender_dir_light(-45.0, 0.0, 10.0)
+    s.rtprop = _rtprop(0, spp, depth)
+    return s
+
+
+def save_obj(scene, path):
+    """Writes a Scene whose instances are all untransformed as OBJ + MTL with full-precision floats (%.9g round-trips fp32), one `o` + `usemtl` per mesh, faces as v/vt/vn
+    with equal indices -- the file `load_obj` turns back into the same buffers.  Test and export helper."""
+    mtl = os.path.splitext(path)[0] + ".mtl"
+    with open(mtl, "w") as f:
+        for i, m in enumerate(scene.materials):
+            f.write("newmtl m%d\nKd %.9g %.9g %.9g\nd %.9g\nPm %.9g\nPr %.9g\nTf %.9g %.9g %.9g\nNi %.9g\n\n" % (
+                i, m["albedo"][0], m["albedo"][1], m["albedo"][2], m["albedo"][3], m["metallic"], m["roughness"],
+                m["transmission"], m["transmission"], m["transmission"], m["ior"]))
+    with open(path, "w") as f:
+        f.write("mtllib %s\n" % os.path.basename(mtl))
+        base = 0
+        for k, (mi, tf, mat) in enumerate(scene.instances):
+            if not np.array_equal(np.asarray(tf, F), np.eye(4, dtype=F)):
+                raise ValueError("save_obj: instance %d is transformed; OBJ has no instancing" % k)
+            v, t, n, uv = scene.meshes[mi]
+            f.write("o mesh%d\nusemtl m%d\n" % (k, mat))
+            for a in v:
+                f.write("v %.9g %.9g %.9g\n" % tuple(a))
+            for a in uv:
+                f.write("vt %.9g %.9g\n" % (a[0], a[1]))
+            for a in n:
+                f.write("vn %.9g %.9g %.9g\n" % tuple(a))
+            for a in t:
+                i0, i1, i2 = (int(x) + base + 1 for x in a)
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (i0, i0, i0, i1, i1, i1, i2, i2, i2))
+            base += v.shape[0]

@@ -222,13 +222,13 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
 
 
-def _build_cpp_sample(tmp_path):
+def _build_cpp_sample(tmp_path, name="cornell_rd"):
     import shutil
     if shutil.which("g++") is None:
         pytest.skip("no g++")
-    exe = str(tmp_path / "cornell_rd")
+    exe = str(tmp_path / name)
     lib_dir = os.path.join(ROOT, "radiance-ray-tracing_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "samples", "cornell_rd.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "samples", name + ".cpp"),
                            "-L" + lib_dir, "-lrdx", "-Wl,-rpath," + lib_dir, "-o", exe])
     return exe
 
@@ -241,4 +241,76 @@ def test_cpp_facade_sample_links_and_fails_loudly_without_gpu(pkg, tmp_path):
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by the gpu suite")
     r = subprocess.run([exe, "32", "18", "1", str(tmp_path / "o.ppm")], capture_output=True, text=True)
+    assert r.returncode == 255 and "Radiance Error" in r.stdout
+
+
+def test_obj_loader(pkg, tmp_path):
+    """rdx_obj_load (csrc/scene_obj.cpp, the assimp-free stand-in for the import in tools/sceneBuilder.cpp:27-258):
+    mesh split at o / usemtl, polygon fans, negative indices, (v, vt, vn) vertex joining in first-use order, smooth
+    normals where the file has none, MTL factors, the default material, offsets in floats -- and the errors"""
+    import rrt_amd
+    from radiance_ray_tracing_amd import rd, scenes
+    obj = tmp_path / "t.obj"
+    (tmp_path / "t.mtl").write_text("newmtl red\nKd 0.8 0.1 0.1\nd 0.5\nPm 0.25\nPr 0.75\nNi 1.33\nTf 0.9 0.9 0.9\n"
+                                    "newmtl shiny\nKd 0.2 0.3 0.4\nNs 250\n")
+    obj.write_text("# comment\nmtllib t.mtl\n"
+                   "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\n"
+                   "o quad\nusemtl red\nf 1/1/1 2/2/1 3/3/1 4/4/1\n"          # one polygon -> 2 triangles, 4 joined vertices
+                   "o tent\nusemtl shiny\nv 0 0 1\nv 2 0 1\nv 1 1 2\nv 1 -1 2\n"
+                   "f -4 -3 -2\nf -3 -4 -1\n"                                   # negative indices, no normals -> smooth
+                   "o bare\nv 5 5 5\nv 6 5 5\nv 5 6 5\nf 9//1 10//1 11//1\n")  # new object keeps the current material
+    s = scenes.load_obj(str(obj), 32, 32, 1, 1)
+    b = s.buffers()
+    assert len(s.meshes) == 3 and [m[1].shape[0] for m in s.meshes] == [2, 2, 1]
+    assert b["meshInfo"]["vertexOffset"].tolist() == [0, 12, 24] and b["meshInfo"]["indexOffset"].tolist() == [0, 6, 12]
+    assert b["meshInfo"]["materialIndex"].tolist() == [0, 1, 1]
+    assert np.array_equal(s.meshes[0][1], [[0, 1, 2], [0, 2, 3]])
+    assert np.array_equal(s.meshes[0][3][:, :2], [[0, 0], [1, 0], [1, 1], [0, 1]]) and np.all(s.meshes[0][2] == [0, 0, 1])
+    # smooth normals: the two shared vertices average both faces, the apexes keep their face normal
+    v, t, n, _ = s.meshes[1]
+    fn = np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]]).astype(np.float64)
+    shared = (fn[0] + fn[1]) / np.linalg.norm(fn[0] + fn[1])
+    assert np.allclose(n[0], shared, atol=1e-6) and np.allclose(n[1], shared, atol=1e-6)
+    assert np.allclose(n[2], fn[0] / np.linalg.norm(fn[0]), atol=1e-6) and np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-6)
+    m = s.materials
+    assert np.allclose(m[0]["albedo"], [0.8, 0.1, 0.1, 0.5]) and np.isclose(m[0]["metallic"], 0.25) and np.isclose(m[0]["roughness"], 0.75)
+    assert np.isclose(m[0]["ior"], 1.33) and np.isclose(m[0]["transmission"], 0.9) and m[0]["albedoTexIdx"] == -1
+    assert np.isclose(m[1]["roughness"], 0.5) and np.isclose(m[1]["ior"], 1.45) and m[1]["transmission"] == 0      # Ns 250 -> 1 - sqrt(.25)
+    # a file without materials gets the default one
+    (tmp_path / "plain.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    p = scenes.load_obj(str(tmp_path / "plain.obj"), 32, 32, 1, 1)
+    assert len(p.materials) == 1 and np.allclose(p.materials[0]["albedo"], [0.6, 0.6, 0.6, 1.0])
+    # round trip of a procedural scene: same triangle soup, same attributes per corner, same materials
+    src = scenes.c1_cornell(32, 18, sphere_subdiv=2)
+    src.instances = [(mi, None if k < 5 else tf, mat) for k, (mi, tf, mat) in enumerate(src.instances)][:5]
+    src.instances = [(mi, np.eye(4, dtype=np.float32), mat) for mi, _, mat in src.instances]
+    scenes.save_obj(src, str(tmp_path / "c1.obj"))
+    back = scenes.load_obj(str(tmp_path / "c1.obj"), 32, 18, 1, 1)
+    assert len(back.meshes) == 5
+    for k in range(5):
+        a, c = src.meshes[src.instances[k][0]], back.meshes[k]
+        for attr in (0, 2, 3):
+            assert np.array_equal(a[attr][a[1]].view(np.uint32), c[attr][c[1]].view(np.uint32)), (k, attr)
+        assert back.instances[k][2] == src.instances[k][2]
+    for a, c in zip(src.materials, back.materials):
+        assert a.tobytes() == c.tobytes()
+    # errors are reported, not swallowed
+    for text, what in (("v 0 0 0\nf 1 2 3\n", "out of range"), ("v 0 0\n", "malformed vertex"), ("usemtl nope\n", "not defined"),
+                       ("mtllib missing.mtl\n", "cannot open material library"), ("v 0 0 0\n", "no faces")):
+        (tmp_path / "bad.obj").write_text(text)
+        with pytest.raises(rd.RadianceError, match=what):
+            scenes.load_obj(str(tmp_path / "bad.obj"))
+    with pytest.raises(rd.RadianceError, match="cannot open"):
+        scenes.load_obj(str(tmp_path / "absent.obj"))
+
+
+def test_cpp_scene_loader_sample_links(pkg, tmp_path):
+    """samples/obj_rd.cpp builds against include/sceneBuilder.h (RD::Scene::Load, INCLUDE_SCENE_DESC / _LAYOUT as the
+    reference's tools/sceneBuilder.h) and, without a device, ends with message + exit(-1)"""
+    import torch
+    exe = _build_cpp_sample(tmp_path, "obj_rd")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu suite")
+    (tmp_path / "plain.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    r = subprocess.run([exe, str(tmp_path / "plain.obj"), "32", "18", str(tmp_path / "o.ppm")], capture_output=True, text=True)
     assert r.returncode == 255 and "Radiance Error" in r.stdout
