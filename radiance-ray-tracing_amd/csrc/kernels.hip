@@ -444,6 +444,9 @@ __device__ __forceinline__ void fill_hit_info(const AccelView& A, uint32_t instS
 #ifndef RDX_SHADE_BLOCK
 #define RDX_SHADE_BLOCK 256
 #endif
+#ifndef RDX_SHADE_OCTANT_BINS
+#define RDX_SHADE_OCTANT_BINS 0       // experiment: measured no gain (sample1 -0.4 %, Sponza-class +1.4 % traversal time)
+#endif
 __global__ void __launch_bounds__(RDX_SHADE_BLOCK, RDX_SHADE_WAVES)
 k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ nOut,
         uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
@@ -484,9 +487,36 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
     // an atomic per wave (130 k of them on one address for a 1080p x 4 spp bounce) serialises in the L2 and was
     // the whole cost of this kernel (1.5 ms whatever the shader did); the block's waves are therefore summed in
     // LDS first and one lane per block moves the cursor.
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+#if RDX_SHADE_OCTANT_BINS
+    // Within the block the survivors are written grouped by the sign octant of their next direction (a counting sort
+    // on 3 bits through LDS): the next bounce's waves then hold rays that start in the same image neighbourhood AND
+    // head the same way, which the traversal rewards (tools/sort_probe.py).  Order never changes a result.
+    constexpr uint32_t NW = RDX_SHADE_BLOCK / 64;
+    __shared__ uint32_t s_cnt[8][NW], s_off[8][NW];
+    const uint32_t key = !alive ? 8u : ((p.nextRayDirection.x < 0.0f ? 1u : 0u) | (p.nextRayDirection.y < 0.0f ? 2u : 0u) |
+                                        (p.nextRayDirection.z < 0.0f ? 4u : 0u));
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t o = 0; o < 8; ++o) {
+        const unsigned long long mo = __ballot(key == o);
+        if (lane == 0) s_cnt[o][wave] = (uint32_t)__popcll(mo);
+        if (key == o) rank = (uint32_t)__popcll(mo & ltMask);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t o = 0; o < 8; ++o) for (uint32_t w = 0; w < NW; ++w) tot += s_cnt[o][w];
+        uint32_t run = tot ? atomicAdd(nOut, tot) : 0u;
+        for (uint32_t o = 0; o < 8; ++o) for (uint32_t w = 0; w < NW; ++w) { s_off[o][w] = run; run += s_cnt[o][w]; }
+    }
+    __syncthreads();
+    if (!alive) return;
+    const uint32_t j = s_off[key][wave] + rank;
+#else
     __shared__ uint32_t s_cnt[RDX_SHADE_BLOCK / 64], s_base;
     const unsigned long long m = __ballot(alive);
-    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -498,7 +528,8 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
     if (!alive) return;
     uint32_t base = s_base;
     for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
-    const uint32_t j = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t j = base + (uint32_t)__popcll(m & ltMask);
+#endif
     const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
     const f3 lit = Cc + T * p.color;               // color += contribution * payload.color (shader.cl:240)
     const f3 occ = Cc + T * p.colorOccluded;
