@@ -457,7 +457,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                         // every instance of the leaf is entered by the reference (no per-instance box test);
                         // instances whose root box the ray provably misses are dropped here (coop_inst_pretest);
                         // its per-ray constants are rebuilt here rather than kept in registers across the walk
-                        const f3 rcpW = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        const f3 rcpW = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));   // 1 ulp: far inside the margin
                         const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
                         const float amax_ = fmaxf(fmaxf(fabsf(rcpW.x), fabsf(rcpW.y)), fabsf(rcpW.z));
                         const float oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
@@ -504,7 +504,10 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 w6 = (w6 & ~((1u << COOP_OWNER_SHIFT) - 1u)) | ci;
                 R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
                 R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
-                R.rcp = mk3(1.0f / R.d.x, 1.0f / R.d.y, 1.0f / R.d.z);
+                // hardware reciprocal (<= 1 ulp) instead of three IEEE divisions: R.rcp only feeds the fast slab test, whose
+                // band covers it -- fl(s/d) and fl(s * rcp) then differ by at most 2^-23 + 2 * 2^-24 = 2^-22 relative, the
+                // band is 4.8e-7 = 2 x 2^-22 of (|tFar| + max(tNear, 0)) -- and the decision inside the band is the division form's
+                R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
                 const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
                 const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
                 R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
