@@ -271,7 +271,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         // (a helper's walk ends like a ray's; an owner additionally waits until its helpers are back)
         const bool stealPhase = COOP_STEAL && (exhausted || quota < 64u);
         if (cur == COOP_NONE && !finishing && !needShade &&
-            (COOP_OWNER() != lane || (rayIdx != COOP_NONE && (!stealPhase || *(volatile uint32_t*)&L.pend[lane] == 0u)))) { finishing = true; finMark = qTail; }
+            (COOP_OWNER() != lane || (rayIdx != COOP_NONE && (!stealPhase || __hip_atomic_load(&L.pend[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u)))) { finishing = true; finMark = qTail; }
         const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
         const bool isFree = (rayIdx == COOP_NONE) && (COOP_OWNER() == lane);
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
