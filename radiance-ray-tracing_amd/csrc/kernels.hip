@@ -1204,4 +1204,13 @@ void launch_pcg3d_batch(hipStream_t st, const uint32_t* in3, float* out3, uint32
     hipLaunchKernelGGL(k_pcg3d_batch, dim3(blocks_for(n, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, in3, out3, n);
 }
 
+#ifdef COOP_STATS
+// experiment builds only (RDX_DEFINES=-DCOOP_STATS): read and clear the step statistics of traverse_coop.h
+extern "C" int rdx_debug_coop_stats(unsigned long long* out16)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_coop_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 } // namespace rdx

@@ -97,6 +97,16 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// COOP_STATS (experiment build only): per step kind, how often it ran and how many lanes it served, summed over the
+// grid into g_coop_stats[kind] / [8 + kind]; kinds: 0 finish/refill, 1 shade, 2 steal, 3 leaf item, 4 top, 5 instance,
+// 6 node, 7 test.  Read back with rdx_debug_coop_stats (tools/coop_stats.py).
+#ifdef COOP_STATS
+__device__ unsigned long long g_coop_stats[16];
+#define COOP_STAT(kind, lanes) do { statN[kind] += 1u; statL[kind] += (uint32_t)(lanes); } while (0)
+#else
+#define COOP_STAT(kind, lanes) do {} while (0)
+#endif
+
 struct CoopLds {
     uint32_t* stack;                 // [need][64]   (already offset by the lane)
     uint32_t* queue;                 // [COOP_QCAP]
@@ -132,6 +142,9 @@ __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds
                                                uint32_t qTail, float tmin, float tmax, const RayInst& R, uint32_t par, uint32_t w6)
 {
     const uint32_t n = min(64u, qTail - qHead);
+#ifdef COOP_STATS
+    if (lane == 0) { atomicAdd(&g_coop_stats[7], 1ull); atomicAdd(&g_coop_stats[15], (unsigned long long)n); }
+#endif
 #ifdef COOP_EXP_NOTEST            // timing experiment (results are wrong): consume the entries without testing them
     qHead += n; return;
 #endif
@@ -242,6 +255,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     uint32_t chunk = min(chunkMax, max(64u, (n / (4u * nWavesGrid)) & ~63u));
     const uint32_t quota = COOP_STEAL ? min(64u, max((uint32_t)COOP_MIN_QUOTA, (n + nWavesGrid - 1u) / nWavesGrid)) : 64u;
 
+#ifdef COOP_STATS
+    uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // wave-uniform
+#endif
     uint32_t qHead = 0, qTail = 0;                         // wave-uniform, monotonically increasing
     bool exhausted = false;                                // wave-uniform: the global counter ran past n and the wave's own
                                                            // reservation is used up
@@ -299,6 +315,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         } while (0)
 
         if (nIdle > 0 && ((stealPhase ? nIdle >= min(nMaxWork, COOP_TAIL_MIN) : nIdle >= nMaxWork + COOP_IDLE_BIAS) || (workMask == 0ull && nShade == 0))) {
+            COOP_STAT(0, __popcll(doneMask) + ((!exhausted) ? __popcll(freeMask) : 0));
             if (done && COOP_OWNER() != lane) {    // a helper is back: its subtree is walked and its queued tests are consumed
                 atomicSub(&L.pend[COOP_OWNER()], 1u);
                 w6 = lane << COOP_OWNER_SHIFT; finishing = false;
@@ -368,6 +385,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         }
         // ---- shade step: every lane whose closest-hit ray found something runs the hit shader together ----
         if (Policy::kShades && nShade > 0 && (nShade >= nMaxWork + COOP_SHADE_BIAS || workMask == 0ull)) {
+            COOP_STAT(1, nShade);
             if (needShade) {
                 bool ah = false;
                 const int act = pol.shade(rayIdx, o, d, ah, st);
@@ -391,6 +409,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             if (pairs > 0 && pairs >= min(COOP_STEAL_MIN, max(1, __popcll(workMask) >> 2))) {
                 // the donors' lane numbers go through the 64 ring slots behind the queue tail
                 if (qTail - qHead + 64u > COOP_QCAP) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+                COOP_STAT(2, pairs);
                 const uint32_t dRank = lanes_below(dMask), sRank = lanes_below(sMask);
                 uint32_t entry = COOP_NONE;
                 if (donor && dRank < (uint32_t)pairs) {
@@ -437,6 +456,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
 
         // ---- queued piece of an oversized leaf, or a leaf root ----------------------------------------
         if (__any(isLeaf)) {
+            COOP_STAT(3, __popcll(__ballot(isLeaf)));
             uint32_t cnt = 0, st = 0;
             if (isLeaf) { st = cur & LEAF_START_MASK; cnt = ((cur >> LEAF_START_BITS) & 7u) + 1u; COOP_POP(); }
             coop_enqueue(A, L, lane, (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT), cnt, st, qHead, qTail, tmin, tmax, R, par, w6);
@@ -444,24 +464,32 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         }
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------
         if (nTop > 0 && nTop >= nNode && nTop >= nInst) {
+            COOP_STAT(4, nTop);
             if (isTop) {
                 const float4* np = reinterpret_cast<const float4*>(A.ctnodes + (cur & IDX_MASK));
                 const float4 bmin = np[0], bmax = np[1];
                 const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
+                // the world ray in the form the fast slab test takes (reciprocal + "exact form only" flag), rebuilt per
+                // visit rather than kept in registers across the walk; the inner-node decision is the reference's
+                // (division form inside the band), as for BLAS nodes
+                RayInst W;
+                W.o = o; W.d = d;
+                W.rcp = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+                const float amax_ = fmaxf(fmaxf(fabsf(W.rcp.x), fabsf(W.rcp.y)), fabsf(W.rcp.z));
+                W.exactOnly = !(amin_ > 1e-20f) || !(amax_ < 1e20f);
                 if (!(w.x & LEAF_BIT)) {
-                    if (slab_hit(o, d, bmin, bmax)) { L.stack[sp * 64u] = TAG_TLAS | w.y; ++sp; cur = TAG_TLAS | w.x; }
+                    if (slab_fast(W, mk3(bmin.x, bmin.y, bmin.z), mk3(bmax.x, bmax.y, bmax.z))) { L.stack[sp * 64u] = TAG_TLAS | w.y; ++sp; cur = TAG_TLAS | w.x; }
                     else COOP_POP();
                 } else {
                     const uint32_t count = w.x & 0x7fffffffu;
                     if (w.z == TYPE_INST) {
                         // every instance of the leaf is entered by the reference (no per-instance box test);
-                        // instances whose root box the ray provably misses are dropped here (coop_inst_pretest);
-                        // its per-ray constants are rebuilt here rather than kept in registers across the walk
-                        const f3 rcpW = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));   // 1 ulp: far inside the margin
-                        const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-                        const float amax_ = fmaxf(fmaxf(fabsf(rcpW.x), fabsf(rcpW.y)), fabsf(rcpW.z));
+                        // instances whose root box the ray provably misses are dropped here (coop_inst_pretest; the
+                        // 1-ulp reciprocal is far inside its margin)
+                        const f3 rcpW = W.rcp;
                         const float oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
-                        const bool preOK = (amin_ > 1e-20f) && (amax_ < 1e20f) && (oMax < 1e20f);
+                        const bool preOK = !W.exactOnly && (oMax < 1e20f);
                         for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
                             uint32_t m16 = 0;
                             for (uint32_t i = 0; i < min(16u, count - b0); ++i)
@@ -480,7 +508,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             // every queued test of it lies before markPrev
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
             if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            COOP_STAT(5, __popcll(__ballot(ready)));
             if (REC != 1) { if (anyHit && ready && L.best[COOP_OWNER()] != ~0ull) { cur = COOP_NONE; sp = 0; } }
+            uint32_t cntE = 0, stE = 0;           // triangles of a leaf-root BLAS, queued at the end of the step
             if (ready && cur != COOP_NONE) {
                 const bool resume = COOP_STEAL && (cur & COOP_RESUME);
                 uint32_t ci = cur & COOP_IFIRST_MASK;
@@ -517,19 +547,24 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 spInst = sp;                 // everything on the stack now is a top-level entry
                 if (resume) { spInst = sp - 1u; COOP_POP(); }
                 else if (rdsc.y & WIDE_LEAF) {
+                    // a BLAS that is a single leaf (a quad, a small box): its triangles are queued right here (below,
+                    // converged) instead of costing a leaf-item step of their own -- 15 % of all steps on sample1
                     uint32_t cnt = rdsc.y & 0x7fffffffu, st = rdsc.x;
                     while (cnt > 8u) { L.stack[sp * 64u] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }
-                    if (cnt) cur = leaf_item(st, cnt); else COOP_POP();
+                    cntE = cnt; stE = st;
+                    COOP_POP();
                 } else {
                     const float4 rmin = ip[10], rmax = ip[11];
                     if (slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z))) cur = rdsc.x;
                     else COOP_POP();
                 }
             }
+            coop_enqueue(A, L, lane, (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT), cntE, stE, qHead, qTail, tmin, tmax, R, par, w6);
             continue;
         }
         // ---- node step ----------------------------------------------------------------------------------------
         if (nodeMask != 0ull) {
+            COOP_STAT(6, nNode);
             uint32_t cntL = 0, stL = 0, cntR = 0, stR = 0, nextL = COOP_NONE, nextR = COOP_NONE;
             if (isNode) {
                 const float4* wp = reinterpret_cast<const float4*>(A.wide + (cur & IDX_MASK));
@@ -564,6 +599,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         // lanes are waiting below their thresholds and nothing else can run: let the queue advance
         if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     }
+#ifdef COOP_STATS
+    if (lane < 7u) { atomicAdd(&g_coop_stats[lane], (unsigned long long)statN[lane]); atomicAdd(&g_coop_stats[8u + lane], (unsigned long long)statL[lane]); }
+#endif
     pol.retire(st);                      // all 64 lanes, converged: per-lane tallies of the policy
 #undef COOP_POP
 #undef COOP_OWNER
