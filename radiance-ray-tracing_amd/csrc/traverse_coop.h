@@ -80,6 +80,12 @@ static_assert(COOP_QCAP >= 512u && (COOP_QCAP & (COOP_QCAP - 1u)) == 0u, "queue 
 #ifndef COOP_TAIL_MIN
 #define COOP_TAIL_MIN 4                // while stealing: finished lanes are handed over as soon as this many wait
 #endif
+#ifndef COOP_W_TOP
+#define COOP_W_TOP 8                   // weight (in quarters) of a lane waiting for a top-level step against one waiting for a node step
+#endif
+#ifndef COOP_W_INST
+#define COOP_W_INST 12                 // the same for the instance step
+#endif
 #ifndef COOP_CHUNK_MAX
 #define COOP_CHUNK_MAX 512u            // most ray indices a wave reserves with one atomic on the global counter (64 = one per refill)
 #endif
@@ -463,7 +469,10 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             continue;
         }
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------
-        if (nTop > 0 && nTop >= nNode && nTop >= nInst) {
+        // The choice between top-level, instance and node step is greedy on WEIGHTED lane counts (quarters): upstream
+        // kinds feed the downstream ones, so serving them a little early keeps more lanes walking than a plain
+        // majority vote, which lets the minority kinds starve behind a stable majority of node lanes
+        if (nTop > 0 && nTop * COOP_W_TOP >= nNode * 4 && nTop * COOP_W_TOP >= nInst * COOP_W_INST) {
             COOP_STAT(4, nTop);
             if (isTop) {
                 const float4* np = reinterpret_cast<const float4*>(A.ctnodes + (cur & IDX_MASK));
@@ -503,7 +512,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
             continue;
         }
         // ---- instance entry (radiance.cl:161-169) ----------------------------------------------------------
-        if (nInst > 0 && nInst >= nNode) {
+        if (nInst > 0 && nInst * COOP_W_INST >= nNode * 4) {
             // the LDS ray slot about to be overwritten belongs to the instance before the previous one:
             // every queued test of it lies before markPrev
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
