@@ -108,6 +108,7 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
 // 6 node, 7 test.  Read back with rdx_debug_coop_stats (tools/coop_stats.py).
 #ifdef COOP_STATS
 __device__ unsigned long long g_coop_stats[16];
+__device__ unsigned long long g_coop_state[8];      // lane-iterations spent in: node, top, inst, leaf, finishing, done, free, iterations*64
 #define COOP_STAT(kind, lanes) do { statN[kind] += 1u; statL[kind] += (uint32_t)(lanes); } while (0)
 #else
 #define COOP_STAT(kind, lanes) do {} while (0)
@@ -263,6 +264,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
 
 #ifdef COOP_STATS
     uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // wave-uniform
+    uint32_t stState[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     uint32_t qHead = 0, qTail = 0;                         // wave-uniform, monotonically increasing
     bool exhausted = false;                                // wave-uniform: the global counter ran past n and the wave's own
@@ -312,6 +314,10 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         const unsigned long long nodeMask = __ballot(isNode), topMask = __ballot(isTop), instMask = __ballot(isInst);
         const int nNode = __popcll(nodeMask), nTop = __popcll(topMask), nInst = __popcll(instMask);
         const int nMaxWork = max(nNode, max(nTop, nInst));
+#ifdef COOP_STATS
+        stState[0] += nNode; stState[1] += nTop; stState[2] += nInst; stState[3] += __popcll(__ballot(isLeaf));
+        stState[4] += __popcll(__ballot(finishing && !done)); stState[5] += __popcll(doneMask); stState[6] += __popcll(freeMask); stState[7] += 64;
+#endif
 
         // (re)start the walk of the ray now in o, d
 #define COOP_START_RAY(WALK) do {                                                                      \
@@ -609,6 +615,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
         if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     }
 #ifdef COOP_STATS
+    if (lane < 8u) atomicAdd(&g_coop_state[lane], (unsigned long long)stState[lane]);
     if (lane < 7u) { atomicAdd(&g_coop_stats[lane], (unsigned long long)statN[lane]); atomicAdd(&g_coop_stats[8u + lane], (unsigned long long)statL[lane]); }
 #endif
     pol.retire(st);                      // all 64 lanes, converged: per-lane tallies of the policy

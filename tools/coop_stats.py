@@ -16,7 +16,7 @@ for cfg, w, h in (("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_co
     s = scenes.CONFIGS[cfg](w, h, 4, 8)
     dev = scenes.DeviceScene(s)
     dev.render()
-    out = (ctypes.c_ulonglong * 16)()
+    out = (ctypes.c_ulonglong * 24)()
     fn(out)                                   # clear what the warm-up frame counted
     dev.set_rtprop(totalSamples=0); dev.render()
     st = rd.GetTraceStats()
@@ -24,6 +24,10 @@ for cfg, w, h in (("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_co
     n = np.array(out[:8], np.float64); l = np.array(out[8:], np.float64)
     rays = st.rays_primary + st.rays_bounce + st.rays_shadow
     print("%s %dx%d: %d rays, %.0f wave-steps (%.1f per 64 rays)" % (cfg, w, h, rays, n.sum(), n.sum() / (rays / 64)))
+    stt = np.array(out[16:24], np.float64)
+    names = ["node", "top", "instance", "leaf", "finishing (tests pending)", "done (waits for hand-over)", "free"]
+    print("  lane states per iteration: " + ", ".join("%s %.1f" % (names[k], 64 * stt[k] / stt[7]) for k in range(7))
+          + ", other %.1f" % (64 - 64 * stt[:7].sum() / stt[7]))
     for k in range(8):
         if n[k]:
             print("  %-14s %5.1f %% of steps, %5.1f lanes / step, %6.2f lane-steps per ray" % (KINDS[k], 100 * n[k] / n.sum(), l[k] / n[k], l[k] / rays))
