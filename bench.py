@@ -279,8 +279,12 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": kernel_name,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[0],
-            "traffic_source": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[1],
+            # HBM bytes per launch from the committed PMC passes of the 1-GPU, full-frame run of this workload (a rank of
+            # an N-GPU run launches on 1/N of the frame: no PMC figure for that)
+            "traffic": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[0]
+                       if world == 1 and (args.width, args.height, args.spp, args.depth) == (1920, 1080, 4, 8) else None,
+            "traffic_source": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[1]
+                              if world == 1 and (args.width, args.height, args.spp, args.depth) == (1920, 1080, 4, 8) else None,
             "algorithmic_bytes_per_launch": int(roof_bytes * steps / launches),
             "avg_launch_ms": round(1e3 * trav_s / launches, 4),
             "launches": launches,
