@@ -17,31 +17,39 @@
 //               tests.  Leaf children are not tested in place: their triangle slots are appended to a
 //               per-wave queue in LDS (offsets from wave64 ballot prefix sums).
 //   test step   when >= 64 triangle tests are queued (or nothing else is left), each lane takes ONE
-//               queue entry -- usually another lane's ray -- reads that ray's object-space origin /
-//               direction from LDS, runs a branch-free Möller–Trumbore with the reference's arithmetic
-//               and publishes an accepted candidate with a 64-bit LDS atomic-min on
-//               (t bits << 32 | instance slot << 22 | BLAS-local triangle slot).
-//   top / instance steps   top-level nodes and instance entries.  Each lane keeps the object-space ray of
-//               its current AND previous instance in LDS (two slots, queue entries carry the slot bit), so
-//               a lane may run one instance ahead of its queued triangle tests.
-//   Which step runs next is greedy: the kind the most lanes are waiting for, so waiting lanes batch up
-//   and every step executes as converged as the moment allows.
+//               queue entry -- usually another lane's ray.  The object-space ray of the entry is fetched from
+//               the walking lane's REGISTERS by lane shuffles (ds_bpermute); only if that lane has meanwhile
+//               entered its next instance (the entry carries the parity of the instance it was queued under)
+//               is it the ray parked in the lane's one LDS slot.  The lane runs a branch-free Möller–Trumbore
+//               with the reference's arithmetic and publishes an accepted candidate with a 64-bit LDS
+//               atomic-min on (t bits << 32 | instance slot << 22 | BLAS-local triangle slot).
+//   top / instance steps   top-level nodes and instance entries.  The instances of a top-level leaf travel as one
+//               16-bit mask entry; entering an instance parks the ray of the instance being left in LDS, so a
+//               lane may run one instance ahead of its queued triangle tests (never two: markPrev).  A BLAS
+//               that is a single leaf has its triangles queued right in the instance step.
+//   Which step runs next is greedy on weighted lane counts: the kind the most lanes are waiting for, upstream
+//   kinds (top, instance) counting 2x / 3x because they feed the node steps; waiting lanes batch up and every
+//   step executes as converged as the moment allows (tools/coop_stats.py prints what the lanes do).
 //   refill step the wave is persistent: a lane whose ray is finished (stack empty and all its queued
-//               tests consumed) writes its result and pulls the next ray index from a global counter
-//               (one wave-aggregated atomic per refill), so lanes do not idle while a long ray of the
-//               same wave is still walking.  The wave leaves when the counter is exhausted, every lane
-//               is idle and the queue is empty -- an exit every wave reaches.
+//               tests consumed) writes its result and takes the next ray index from the wave's reservation,
+//               which is refilled from a global counter in chunks (guided self-scheduling), so lanes do not
+//               idle while a long ray of the same wave is still walking.  The wave leaves when the counter is
+//               exhausted, every lane is idle and the queue is empty -- an exit every wave reaches.
 //
 //   steal step  subtree sharing inside the wave.  Because nothing is culled by the best t, the subtrees on a
 //               lane's stack are independent pieces of work whose only output is the atomic-min key of
 //               the ray's owner -- so ANY lane may walk them.  Once the wave cannot get new rays (global
-//               counter exhausted) or was handed fewer than 64 rays (small launches are spread over the whole
-//               chip, `quota` rays per wave), free lanes take the bottom entry of a busy lane's stack (the
-//               largest pending subtree) and walk it on behalf of that ray: the world ray comes over by
-//               lane shuffles, the object-space ray by copying the donor's LDS ray slot, candidates go to
-//               best[owner], and the owner hands its result over only when its helper count is back to 0.
-//               Helpers donate in turn, so one long ray spreads over the wave in a few steps and the tail of a
-//               launch is bounded by the wave's remaining WORK / 64 instead of by its longest ray.
+//               counter exhausted), free lanes take the bottom entry of a busy lane's stack (the largest
+//               pending subtree) and walk it on behalf of that ray: the world ray comes over by lane shuffles,
+//               a stolen BLAS-level entry re-enters the donor's instance through the ordinary instance step
+//               (same matrix, same world ray => the same object-space ray), candidates go to best[owner], and
+//               the owner hands its result over only when its helper count is back to 0.  Helpers donate in
+//               turn, so one long ray spreads over the wave in a few steps and the tail of a launch is bounded
+//               by the wave's remaining WORK / 64 instead of by its longest ray.
+//
+// LDS per wave = (stack need + 18) * 256 B: the stack [need][64], the 512-entry queue ring, the parked rays
+// [7][64], best[64] (64-bit) and the helper counts [64].  Residency is LDS-bound and the kernel lives on residency
+// (tools/occupancy_probe.sh), hence the small stack need (derive_accel: smaller subtree first) and the single slot.
 //
 // Any-hit (shadow) rays use the same machinery and drop their remaining work as soon as a candidate
 // has been published.
@@ -56,7 +64,7 @@ namespace rdx {
 #define COOP_QCAP 512u                 // queue ring capacity in entries: a power of two, and one enqueue (64 lanes x 8) must fit
 #endif
 static_assert(COOP_QCAP >= 512u && (COOP_QCAP & (COOP_QCAP - 1u)) == 0u, "queue ring too small for one enqueue");
-#define COOP_LANE_SHIFT 26u            // queue entry = owner lane << 26 | ray-slot bit << 25 | absolute triangle slot
+#define COOP_LANE_SHIFT 26u            // queue entry = walking lane << 26 | instance parity << 25 | absolute triangle slot
 #define COOP_PAR_SHIFT 25u
 #define COOP_SLOT_MASK ((1u << 25) - 1u)
 #define COOP_INST_SHIFT 22u            // key low word = instance slot << 22 | BLAS-local triangle slot
