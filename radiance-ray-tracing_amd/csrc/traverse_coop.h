@@ -88,6 +88,12 @@ static_assert(COOP_QCAP >= 512u && (COOP_QCAP & (COOP_QCAP - 1u)) == 0u, "queue 
 #ifndef COOP_TAIL_MIN
 #define COOP_TAIL_MIN 4                // while stealing: finished lanes are handed over as soon as this many wait
 #endif
+#ifndef COOP_WATCHDOG
+#define COOP_WATCHDOG 0               // debug builds: bound the iterations of a wave (costs ~3 % through code placement alone)
+#endif
+#ifndef COOP_MAX_ITER
+#define COOP_MAX_ITER (1u << 24)
+#endif
 #ifndef COOP_W_TOP
 #define COOP_W_TOP 8                   // weight (in quarters) of a lane waiting for a top-level step against one waiting for a node step
 #endif
@@ -290,6 +296,9 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     uint32_t markPrev = 0;                                 // qTail when the previous instance was left
     uint32_t finMark = 0; bool finishing = false;
     bool anyHit = (REC == 2);                              // this lane's ray ends at its first accepted candidate
+#if COOP_WATCHDOG
+    uint32_t iter = 0;
+#endif
     bool needShade = false;                                // the lane's item waits for a shade step
     typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
@@ -299,6 +308,12 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
 #define COOP_POP() do { if (sp == 0) cur = COOP_NONE; else { --sp; cur = L.stack[sp * 64u]; } } while (0)
 
     for (;;) {
+#if COOP_WATCHDOG
+        // watchdog (wave-uniform, scalar): three orders of magnitude above what any launch needs; a wave that gets here
+        // leaves with work undone rather than spin (results are then wrong, which the parity tests would show)
+        iter = __builtin_amdgcn_readfirstlane(iter + 1u);
+        if (iter > COOP_MAX_ITER) break;
+#endif
         // ---- lanes whose walk has ended wait for their queued tests, then hand the result over ----
         // (a helper's walk ends like a ray's; an owner additionally waits until its helpers are back)
         const bool stealPhase = COOP_STEAL && (exhausted || quota < 64u);
