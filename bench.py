@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse", type=int, default=-1, help="-1 auto, 0/1: shadow(d)+extend(d+1) in one launch")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 library default, 0 staged wavefront, 1 whole paths in one persistent launch")
+    ap.add_argument("--kernel", type=int, default=-1, help="-1 library default; 2 cooperative, 3 cooperative with a shared node pool, 1 / 0 per-lane")
     ap.add_argument("--also", default="", help="comma list of extra workloads to time (reported under 'also')")
     args = ap.parse_args()
 
@@ -169,6 +170,8 @@ def main():
     rd.SetOption("fuse", args.fuse)
     if args.pipeline >= 0:
         rd.SetOption("pipeline", args.pipeline)
+    if args.kernel >= 0:
+        rd.SetOption("kernel", args.kernel)
 
     def run_workload(key, steps, warmup, want_roofline):
         cfg, label = WORKLOADS[key]

@@ -154,9 +154,10 @@ int         rdx_get_bounce_counts(uint64_t* out, uint32_t n);
 /* 0 = per-stage HIP events off (default), 1 = on (adds launch gaps; for profiling only) */
 int         rdx_set_profiling(int on);
 /* knobs: "chunk_paths" (paths in flight per chunk), "count_visits" (0/1: also count node /
- * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 2 = wave-
- * cooperative (default), 1 = per-lane wide nodes, 0 = reference order; all three give identical
- * results, the option exists for A/B measurements and cross-checks), "pipeline" (0 = staged
+ * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 3 = wave-
+ * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
+ * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
+ * cross-checks), "pipeline" (0 = staged
  * wavefront: one launch per stage per bounce (default); 1 = whole paths -- camera ray to path end -- in one
  * persistent cooperative launch per sample chunk), "fuse" (1 / -1 = on (default), 0 = off:
  * trace the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch, which

@@ -318,6 +318,7 @@ __device__ __forceinline__ void traverse_wide(const AccelView& A, f3 o, f3 d, fl
 
 } // namespace rdx
 #include "traverse_coop.h"
+#include "traverse_pool.h"
 namespace rdx {
 
 extern __shared__ uint32_t s_stack[];
@@ -795,6 +796,34 @@ k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
     traverse_coop<3>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
+// ---- the same three launches on the shared-node-pool engine (traverse_pool.h, `kernel` option 3) ------------------------
+__global__ void COOP_BOUNDS
+k_extend_pool(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
+{
+    ExtendPolicy pol{A, ps};
+    traverse_pool<1>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+
+__global__ void COOP_BOUNDS
+k_shadow_pool(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
+              uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
+{
+    const float* ld = sc.scene->lights[0].direction;
+    ShadowPolicy pol{A, ps, normalize3(mk3(-ld[0], -ld[1], -ld[2])), lastBounce, nPixels, sampleBase};
+    traverse_pool<2>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+
+__global__ void COOP_BOUNDS
+k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
+             uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
+{
+    const float* ld = sc.scene->lights[0].direction;
+    const uint32_t m = *mPtr;
+    FusedPolicy pol{ShadowPolicy{A, psShadow, normalize3(mk3(-ld[0], -ld[1], -ld[2])), 0u, nPixels, sampleBase},
+                    ExtendPolicy{A, psExtend}, m};
+    traverse_pool<3>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+
 // ---------------------------------------------------------------------------------------------
 // whole paths on the cooperative engine: one launch per chunk of samples
 // ---------------------------------------------------------------------------------------------
@@ -940,6 +969,15 @@ k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __rest
     traverse_coop<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
+template <int REC>
+__global__ void COOP_BOUNDS
+k_trace_batch_pool(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
+                   float tmin, float tmax, rdx_hit* __restrict__ out)
+{
+    BatchPolicy pol{A, o, d, out};
+    traverse_pool<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+
 // ---------------------------------------------------------------------------------------------
 // test seams
 // ---------------------------------------------------------------------------------------------
@@ -1038,13 +1076,16 @@ void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& p
 }
 
 // threads per block for the cooperative kernels: per-wave LDS = stack + queue + ray table
-static inline uint32_t coop_threads(uint32_t need, size_t& ldsBytes)
+static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsBytes);
+static inline uint32_t coop_threads(uint32_t need, size_t& ldsBytes) { return coop_threads_words(coop_words_per_wave(need), ldsBytes); }
+static inline uint32_t pool_threads(const AccelView& av, size_t& ldsBytes) { return coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), ldsBytes); }
+static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsBytes)
 {
     // experiment knobs (tools/occupancy_probe.sh): RDX_COOP_THREADS = block size, RDX_COOP_LDS_PAD = extra LDS bytes per
     // wave (lowers the residency the LDS allows)
     static const int envThreads = std::getenv("RDX_COOP_THREADS") ? std::atoi(std::getenv("RDX_COOP_THREADS")) : 0;
     static const int envPad = std::getenv("RDX_COOP_LDS_PAD") ? std::atoi(std::getenv("RDX_COOP_LDS_PAD")) : 0;
-    const size_t perWave = (size_t)coop_words_per_wave(need) * 4 + (size_t)envPad;
+    const size_t perWave = (size_t)wordsPerWave * 4 + (size_t)envPad;
     // Residency is LDS-bound (tools/occupancy_probe.sh: frame time falls steadily up to the 5 waves / SIMD the
     // registers allow), so take the block size -- 4 or 2 waves -- that packs the most waves into a CU's 160 KB.
     uint32_t threads = 64;
@@ -1076,6 +1117,11 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
                    float tmin, float tmax, unsigned long long* visit, uint32_t* counter)
 {
     if (!nMax) return;
+    if (!visit && av.kernel == 3) {
+        size_t lds; const uint32_t th = pool_threads(av, lds);
+        hipLaunchKernelGGL(k_extend_pool, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
+        return;
+    }
     if (!visit && av.kernel == 2) {
         size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
         hipLaunchKernelGGL(k_extend_coop, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
@@ -1101,6 +1147,12 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
                    unsigned long long* visit, uint32_t* counter)
 {
     if (!nMax) return;
+    if (!visit && av.kernel == 3) {
+        size_t ldsc; const uint32_t thc = pool_threads(av, ldsc);
+        hipLaunchKernelGGL(k_shadow_pool, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
+                           lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
+        return;
+    }
     if (!visit && av.kernel == 2) {
         size_t ldsc; const uint32_t thc = coop_threads(av.coopNeed, ldsc);
         hipLaunchKernelGGL(k_shadow_coop, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
@@ -1120,6 +1172,12 @@ void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
                   const uint32_t* mPtr, uint32_t mMax, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, uint32_t* counter)
 {
     if (!mMax) return;
+    if (av.kernel == 3) {
+        size_t ldsp; const uint32_t thp = pool_threads(av, ldsp);
+        hipLaunchKernelGGL(k_fused_pool, dim3(coop_blocks(2u * mMax, thp, ldsp)), dim3(thp), ldsp, st, av, sc, psShadow, psExtend, mPtr,
+                           counter, nPixels, sampleBase, tmin, tmax);
+        return;
+    }
     size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
     hipLaunchKernelGGL(k_fused_coop, dim3(coop_blocks(2u * mMax, th, lds)), dim3(th), lds, st, av, sc, psShadow, psExtend, mPtr,
                        counter, nPixels, sampleBase, tmin, tmax);
@@ -1166,6 +1224,13 @@ void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, con
                         float tmax, int rec, rdx_hit* out, unsigned long long* visit, int mode, uint32_t* counter)
 {
     if (!n) return;
+    if (!visit && mode == 0 && av.kernel == 3) {
+        size_t ldsp; const uint32_t thp = pool_threads(av, ldsp);
+        const dim3 gp(coop_blocks(n, thp, ldsp));
+        if (rec == 2) hipLaunchKernelGGL(k_trace_batch_pool<2>, gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
+        else hipLaunchKernelGGL(k_trace_batch_pool<1>, gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
+        return;
+    }
     if (!visit && mode == 0 && av.kernel == 2) {
         size_t ldsc; const uint32_t thc = coop_threads(av.coopNeed, ldsc);
         const dim3 gc(coop_blocks(n, thc, ldsc));

@@ -35,6 +35,7 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     DWide* wide = nullptr;
     uint32_t stackNeed = 1;            // per-lane kernels (reference order: left child followed, right child pushed)
     uint32_t coopNeed = 1;             // wave-cooperative kernel (leaf children are never pushed, smaller subtree first)
+    uint32_t topNeed = 1, blasNeed = 0; // its two parts: top-level entries of one ray / entries inside one BLAS (pool engine)
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
     void release()
     {
@@ -102,7 +103,7 @@ struct Context {
     // options
     int64_t chunkPaths = 16ll << 20;
     bool countVisits = false, profiling = false;
-    int kernel = 2;                         // traversal kernel: 2 cooperative, 1 per-lane wide, 0 reference order
+    int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
     rdx_trace_stats stats{};
     uint32_t visitDepth = 0;                // bounces covered by hVisit after a count_visits frame
@@ -309,7 +310,8 @@ int derive_accel(rdx_buffer_s* tb)
     // stack need: TLAS part
     // (cooperative kernel: the instances of a top-level leaf are pushed as 16-bit masks, one entry per 16 instances,
     //  and the entry being consumed is pushed back while one of its instances is walked)
-    std::vector<uint32_t> needT(nTop, 0), needC(nTop, 0);
+    std::vector<uint32_t> needT(nTop, 0), needC(nTop, 0), needTopOnly(nTop, 0);
+    uint32_t maxBlasCoop = 0;
     std::vector<DNode> dTc(dT);
     for (uint32_t i = nTop; i-- > 0;) {
         const BlobNode& n = tnodes[i];
@@ -320,6 +322,8 @@ int derive_accel(rdx_buffer_s* tb)
                 const BlasInfo& bi = blasAt[binst[n.w1 + k].instanceOffset];
                 mx = std::max(mx, bi.need); mxc = std::max(mxc, bi.coopNeed);
             }
+            maxBlasCoop = std::max(maxBlasCoop, mxc);
+            needTopOnly[i] = (cnt + 15u) / 16u;
             needT[i] = (cnt ? cnt - 1 : 0) + mx;
             needC[i] = (cnt + 15u) / 16u + mxc;
         } else {
@@ -327,12 +331,15 @@ int derive_accel(rdx_buffer_s* tb)
             // cooperative kernel: its own copy of the top-level nodes with the smaller-need child in the followed slot
             if (needC[n.w1] < needC[n.w0]) std::swap(dTc[i].w0, dTc[i].w1);
             needC[i] = std::max(1u + needC[dTc[i].w0], needC[dTc[i].w1]);
+            needTopOnly[i] = std::max(1u + needTopOnly[dTc[i].w0], needTopOnly[dTc[i].w1]);
         }
     }
     auto ac = std::make_unique<AccelCache>();
     ac->stackNeed = std::max(1u, needT[0]) + 1u + maxLeafChunks;
     // oversized leaves are cut into 8-triangle work items: all but the first piece of each child are pushed
     ac->coopNeed = std::max(1u, needC[0]) + 1u + 2u * ((std::max(maxLeafTris, 1u) + 7u) / 8u - 1u);
+    ac->topNeed = std::max(1u, needTopOnly[0]) + 1u;
+    ac->blasNeed = maxBlasCoop;
     if (ac->stackNeed > 2560) return fail("BVH too deep for the LDS traversal stack (%u entries)", ac->stackNeed);
     auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
@@ -349,8 +356,8 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->wide, dW));
     ac->coopOK = coopOK && dTri.size() < (1u << 26);
     if (std::getenv("RDX_VERBOSE"))
-        std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u)\n",
-                     nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed);
+        std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u = top %u + BLAS %u)\n",
+                     nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed, ac->topNeed, ac->blasNeed);
     ac->version = tb->version;
     if (tb->accel) tb->accel->release();
     tb->accel = std::move(ac);
@@ -362,9 +369,10 @@ AccelView view_of(const rdx_buffer_s* tb)
     AccelView v{};
     v.tnodes = tb->accel->tnodes; v.ctnodes = tb->accel->ctnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
     v.wide = tb->accel->wide;
-    v.kernel = (g.kernel == 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
+    v.kernel = (g.kernel >= 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
     v.stackNeed = tb->accel->stackNeed;
     v.coopNeed = tb->accel->coopNeed;
+    v.topNeed = tb->accel->topNeed; v.blasNeed = tb->accel->blasNeed;
     return v;
 }
 
@@ -844,7 +852,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "overlap")) { if (value < 0 || value > 1) return fail("overlap must be 0 or 1"); g.overlap = (int)value; return 0; }
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
-    if (!strcmp(name, "kernel")) { if (value < 0 || value > 2) return fail("kernel must be 0, 1 or 2"); g.kernel = (int)value; return 0; }
+    if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
 }
 extern "C" int rdx_get_bounce_counts(uint64_t* out, uint32_t n)
@@ -931,12 +939,12 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         // Small chunks (multi-GPU shards, low resolutions): a traversal launch costs ~0.2 ms of ramp + tail
         // whatever its size (tools/trav_scale.py), so shadow(d) and extend(d+1) -- same ray count, disjoint
         // streams -- go into ONE cooperative launch: 9 traversal launches per depth-8 frame instead of 16.
-        const bool fuse = g.fuse != 0 && !visit && av.kernel == 2;
+        const bool fuse = g.fuse != 0 && !visit && av.kernel >= 2;
         (void)small;
         const bool overlap = g.overlap == 1 && !fuse && !visit;
         HIP_OK(hipEventRecord(g.evChunk, g.stream));          // everything before this chunk (previous accumulate) is done first
 
-        if (g.pathMode == 1 && !visit && av.kernel == 2 && maxDepth > 0) {
+        if (g.pathMode == 1 && !visit && av.kernel >= 2 && maxDepth > 0) {
             // ---- whole paths in one persistent launch (k_path_coop) + accumulate ----
             Context::Group& G = g.groups[0];
             const uint32_t n0 = sc_n * P;

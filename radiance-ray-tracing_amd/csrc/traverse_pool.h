@@ -1,0 +1,319 @@
+// traverse_pool.h -- the wave-cooperative traversal with a SHARED node pool (experimental engine, `kernel` option 3).
+//
+// tools/coop_stats.py shows where traverse_coop.h leaves lanes idle: a test step serves 62-64 lanes because any lane
+// may test any queued (ray, triangle) pair, but a node step only serves the lanes whose OWN ray holds a BLAS node at
+// that moment -- 29-33 of 64.  Here BLAS nodes get the treatment the triangles already have.  Nothing is culled by
+// the best t, so a pending (ray, node) pair is an independent work item whose only outputs are more such items and
+// queued triangle tests: all of a wave's pending BLAS nodes live in ONE LIFO pool in LDS and every pool step pops up
+// to 64 of them, whichever rays they belong to.  The lane that processes an item fetches the object-space ray of the
+// item's ray from the owning lane's registers by lane shuffles, runs the two slab tests of the wide node with the
+// reference's decision rule, pushes inner children back, queues leaf triangles for the owner and adjusts the owner's
+// count of outstanding items (LDS atomic).  A lane is the top-level driver of its ray: it walks the TLAS and enters
+// instances itself (private stack of top-level entries), pushes the BLAS root into the pool and waits until its
+// count is back to zero before it moves on, so a ray has one instance in the pool at a time and the parity logic of
+// the test queue (traverse_coop.h) carries over unchanged.
+//
+// Pool capacity.  Popping k items can push at most 2k, so the pool grows by at most k per step.  With
+// RESERVE = BLAS stack need + 3 free entries kept back, a step pops min(64, items, free - RESERVE) items; when that is
+// < 1 it pops exactly one (depth-first mode), whose subtree never needs more than need + 1 entries above it.  The pool
+// therefore never overflows whatever its size; 64 * (need + 2) entries keep it in wide mode in practice.
+#pragma once
+
+namespace rdx {
+
+#ifndef POOL_EXTRA
+#define POOL_EXTRA 0u                  // pool capacity = 64 * (BLAS stack need + POOL_EXTRA) entries (0: 20 waves / CU on the Sponza-class scene)
+#endif
+__host__ __device__ inline uint32_t pool_cap(uint32_t blasNeed) { return 64u * (blasNeed + POOL_EXTRA) < 128u ? 128u : 64u * (blasNeed + POOL_EXTRA); }
+__host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32_t blasNeed)
+{
+    return topNeed * 64u + pool_cap(blasNeed) + 64u + COOP_QCAP + COOP_RAY_WORDS * 64u + 128u;
+}
+
+#define POOL_LANE_SHIFT 26u            // pool item = owning lane << 26 | wide-node index
+#define POOL_NODE_MASK ((1u << POOL_LANE_SHIFT) - 1u)
+#define POOL_INBLAS 0xfffffffeu        // top-level cursor of a lane whose instance is in the pool
+#ifndef POOL_IDLE_MIN
+#define POOL_IDLE_MIN 32               // finished / free lanes a hand-over step waits for (16: +13 %, 24: +4 %, 40-48: +0-3 % frame time)
+#endif
+
+template <int REC, class Policy>
+__device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
+                                              float tmin, float tmax, uint32_t* __restrict__ lds)
+{
+    static_assert(!Policy::kShades, "the pool engine has no shade step");
+    const uint32_t lane = __lane_id();
+    const uint32_t PCAP = pool_cap(A.blasNeed), RESERVE = A.blasNeed + 3u;
+    uint32_t* tstack = lds + lane;                         // [level * 64]: top-level entries of this lane's ray
+    uint32_t* pool = lds + A.topNeed * 64u;
+    uint32_t* pendN = pool + PCAP;                         // [64] outstanding pool items of the lane's current instance
+    CoopLds L;
+    L.stack = nullptr;
+    L.queue = pendN + 64;
+    L.ray = reinterpret_cast<float*>(L.queue + COOP_QCAP);
+    L.best = reinterpret_cast<unsigned long long*>(L.ray + COOP_RAY_WORDS * 64u);
+    L.pend = nullptr;
+    pendN[lane] = 0u;
+
+    const uint32_t nWavesGrid = gridDim.x * (blockDim.x >> 6);
+    const uint32_t chunkMax = (REC == 1) ? 64u : (uint32_t)COOP_CHUNK_MAX;
+    uint32_t chunk = min(chunkMax, max(64u, (n / (4u * nWavesGrid)) & ~63u));
+
+    uint32_t qHead = 0, qTail = 0, poolTop = 0;            // wave-uniform
+    bool exhausted = false, lastOfAll = false;
+    uint32_t resBase = 0, resEnd = 0;
+    uint32_t rayIdx = COOP_NONE;
+    uint32_t tcur = COOP_NONE, tsp = 0;                    // top-level cursor / stack pointer
+    uint32_t par = 0, w6 = lane << COOP_OWNER_SHIFT;
+    uint32_t markPrev = 0, finMark = 0;
+    bool finishing = false, anyHit = (REC == 2);
+    typename Policy::State st{};
+    f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+    RayInst R;
+    R.o = o; R.d = d; R.rcp = mk3(0.f, 0.f, 0.f); R.exactOnly = true;
+
+#define POOL_TPOP() do { if (tsp == 0) tcur = COOP_NONE; else { --tsp; tcur = tstack[tsp * 64u]; } } while (0)
+#define POOL_START_RAY(WALK) do {                                                                      \
+        L.best[lane] = ~0ull;                                                                          \
+        tsp = 0; par = 0; markPrev = qHead; finishing = false;                                         \
+        tcur = (WALK) ? (TAG_TLAS | 0u) : COOP_NONE;                                                   \
+    } while (0)
+
+#if COOP_WATCHDOG
+    uint32_t iter = 0;
+#endif
+    for (;;) {
+#if COOP_WATCHDOG
+        iter = __builtin_amdgcn_readfirstlane(iter + 1u);
+        if (iter > COOP_MAX_ITER) break;
+#endif
+        // a lane whose instance has left the pool moves on along its top-level stack
+        if (tcur == POOL_INBLAS && pendN[lane] == 0u) POOL_TPOP();
+        if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }
+        const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
+        const bool isFree = (rayIdx == COOP_NONE);
+        const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
+        const bool has = (tcur != COOP_NONE) && (tcur != POOL_INBLAS);
+        const uint32_t tag = tcur & TAG_MASK;
+        const bool isTop = has && tag == TAG_TLAS, isInst = has && tag == TAG_INST;
+        const int nTop = __popcll(__ballot(isTop)), nInst = __popcll(__ballot(isInst));
+        const int nPool = (int)min(64u, poolTop);
+        const bool workAny = (nTop | nInst) != 0 || poolTop != 0u;
+        const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
+
+        // ---- hand-over: finished rays are written out, free lanes take new rays -----------------------------------
+        // (the pool usually holds 64+ items, so -- unlike traverse_coop.h -- the trigger is an absolute number of idle lanes)
+        if (nIdle > 0 && (nIdle >= POOL_IDLE_MIN || !workAny)) {
+            if (done) {
+                Best B;
+                B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
+                const unsigned long long key = L.best[lane];
+                if (key != ~0ull) {
+                    const uint32_t low = (uint32_t)key;
+                    const uint32_t inst = low >> COOP_INST_SHIFT;
+                    const DInst& I = A.insts[inst];
+                    B.slot = I._p0 + (low & COOP_LOCAL_MASK);
+                    B.hit = true; B.inst = inst;
+                    B.t = __uint_as_float((uint32_t)(key >> 32));
+                    if (!anyHit) {       // b1 / b2 recomputed with the arithmetic of the accepting test
+                        const f3 ro = mat4_mul3(I.inv, o.x, o.y, o.z, 1.0f);
+                        const f3 rd = mat4_mul3(I.inv, d.x, d.y, d.z, 0.0f);
+                        float t, b1, b2;
+                        coop_triangle(A, B.slot, ro, rd, tmin, tmax, t, b1, b2);
+                        B.t = t; B.b1 = b1; B.b2 = b2;
+                    }
+                }
+                bool ah = anyHit;
+                const int act = pol.finish(rayIdx, B, o, d, ah, st);
+                finishing = false;
+                if (act == COOP_RELEASE) rayIdx = COOP_NONE;
+                else { anyHit = (REC == 2) || (REC == 3 && ah); POOL_START_RAY(true); }
+            }
+            if (!exhausted) {
+                const bool want = (rayIdx == COOP_NONE);
+                const unsigned long long wm = __ballot(want);
+                uint32_t cnt = (uint32_t)__popcll(wm);
+                if (cnt) {
+                    if (resBase == resEnd) {                // reserve a chunk of ray indices (guided self-scheduling, traverse_coop.h)
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(counter, chunk);
+                        b = __builtin_amdgcn_readfirstlane(b);
+                        resBase = min(b, n); resEnd = min(b + chunk, n);
+                        lastOfAll = (b + chunk >= n);
+                        const uint32_t left = n - resEnd;
+                        chunk = min(chunkMax, max(64u, (left / (4u * nWavesGrid)) & ~63u));
+                    }
+                    cnt = min(cnt, resEnd - resBase);
+                    const uint32_t base = resBase;
+                    resBase += cnt;
+                    if (resBase == resEnd && lastOfAll) exhausted = true;
+                    const uint32_t rank = lanes_below(wm);
+                    if (want && rank < cnt) {
+                        const uint32_t idx = base + rank;
+                        rayIdx = idx;
+                        bool ah = false;
+                        const bool walk = pol.load(idx, o, d, ah, st);
+                        anyHit = (REC == 2) || (REC == 3 && ah);
+                        POOL_START_RAY(walk);
+                    }
+                }
+            }
+            continue;
+        }
+        if (!workAny) {
+            if (qTail != qHead) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            if (__ballot(rayIdx != COOP_NONE) == 0ull) break;      // exhausted, every lane free, queue and pool empty
+            continue;                                              // lanes still finishing: next round hands them over
+        }
+        if (qTail - qHead >= 64u) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+
+        // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------------------
+        if (nTop > 0 && nTop * COOP_W_TOP >= nPool * 4 && nTop * COOP_W_TOP >= nInst * COOP_W_INST) {
+            if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
+            if (isTop && tcur != COOP_NONE) {
+                const float4* np = reinterpret_cast<const float4*>(A.ctnodes + (tcur & IDX_MASK));
+                const float4 bmin = np[0], bmax = np[1];
+                const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
+                RayInst W;
+                W.o = o; W.d = d;
+                W.rcp = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+                const float amax_ = fmaxf(fmaxf(fabsf(W.rcp.x), fabsf(W.rcp.y)), fabsf(W.rcp.z));
+                W.exactOnly = !(amin_ > 1e-20f) || !(amax_ < 1e20f);
+                if (!(w.x & LEAF_BIT)) {
+                    if (slab_fast(W, mk3(bmin.x, bmin.y, bmin.z), mk3(bmax.x, bmax.y, bmax.z))) { tstack[tsp * 64u] = TAG_TLAS | w.y; ++tsp; tcur = TAG_TLAS | w.x; }
+                    else POOL_TPOP();
+                } else {
+                    const uint32_t count = w.x & 0x7fffffffu;
+                    if (w.z == TYPE_INST) {
+                        const float oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+                        const bool preOK = !W.exactOnly && (oMax < 1e20f);
+                        for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
+                            uint32_t m16 = 0;
+                            for (uint32_t i = 0; i < min(16u, count - b0); ++i)
+                                if (coop_inst_pretest(A.insts[w.y + b0 + i], o, W.rcp, oMax, preOK)) m16 |= 1u << i;
+                            if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                        }
+                    }
+                    POOL_TPOP();
+                }
+            }
+            continue;
+        }
+        // ---- instance entry (radiance.cl:161-169): the BLAS root goes into the pool ----------------------------------
+        if (nInst > 0 && nInst * COOP_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE) {
+            const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
+            if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
+            uint32_t cntE = 0, stE = 0, rootNode = COOP_NONE;
+            if (ready && tcur != COOP_NONE) {
+                uint32_t ci = tcur & COOP_IFIRST_MASK;
+                {
+                    const uint32_t m16 = (tcur >> COOP_IMASK_SHIFT) & 0xffffu, rest = m16 & (m16 - 1u);
+                    ci += (uint32_t)__ffs((int)m16) - 1u;
+                    if (rest) { tstack[tsp * 64u] = TAG_INST | (rest << COOP_IMASK_SHIFT) | (tcur & COOP_IFIRST_MASK); ++tsp; }
+                }
+                const float4* ip = reinterpret_cast<const float4*>(A.insts + ci);
+                float m[16];
+                *reinterpret_cast<float4*>(m + 0) = ip[0];
+                *reinterpret_cast<float4*>(m + 4) = ip[1];
+                *reinterpret_cast<float4*>(m + 8) = ip[2];
+                *reinterpret_cast<float4*>(m + 12) = ip[3];
+                {   // park the ray of the instance being left: queued tests of it may still be pending
+                    float* rs = L.ray + lane;
+                    rs[0 * 64] = R.o.x; rs[1 * 64] = R.o.y; rs[2 * 64] = R.o.z;
+                    rs[3 * 64] = R.d.x; rs[4 * 64] = R.d.y; rs[5 * 64] = R.d.z;
+                    rs[6 * 64] = __uint_as_float(w6);
+                }
+                w6 = (w6 & ~((1u << COOP_OWNER_SHIFT) - 1u)) | ci;
+                R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
+                R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
+                R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
+                const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
+                const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
+                R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
+                const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
+                markPrev = qTail;            // everything queued so far belongs to instances being left
+                par ^= 1u;
+                if (rdsc.y & WIDE_LEAF) {
+                    cntE = rdsc.y & 0x7fffffffu; stE = rdsc.x;
+                    POOL_TPOP();
+                } else {
+                    const float4 rmin = ip[10], rmax = ip[11];
+                    if (slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z))) { rootNode = rdsc.x; pendN[lane] = 1u; tcur = POOL_INBLAS; }
+                    else POOL_TPOP();
+                }
+            }
+            {
+                const unsigned long long pm = __ballot(rootNode != COOP_NONE);
+                if (rootNode != COOP_NONE) pool[poolTop + lanes_below(pm)] = (lane << POOL_LANE_SHIFT) | (rootNode & POOL_NODE_MASK);
+                poolTop += (uint32_t)__popcll(pm);
+            }
+            const uint32_t tagBits = (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT);
+            while (__any(cntE != 0u)) {      // (a leaf of more than 8 triangles goes in pieces)
+                const uint32_t c = min(cntE, 8u);
+                coop_enqueue(A, L, lane, tagBits, c, stE, qHead, qTail, tmin, tmax, R, par, w6);
+                stE += c; cntE -= c;
+            }
+            continue;
+        }
+        // ---- pool step: up to 64 pending BLAS nodes, whichever rays they belong to -----------------------------------
+        if (poolTop != 0u) {
+            const uint32_t freeE = PCAP - poolTop;
+            const uint32_t npop = min(min(64u, poolTop), freeE > RESERVE ? freeE - RESERVE : 1u);
+            const bool valid = lane < npop;
+            const uint32_t item = valid ? pool[poolTop - 1u - lane] : (lane << POOL_LANE_SHIFT);
+            poolTop -= npop;
+            const uint32_t wl = item >> POOL_LANE_SHIFT;
+            // the object-space ray of the item's owner, from its registers
+            const uint32_t myFlags = (R.exactOnly ? 1u : 0u) | (par << 1) | (anyHit ? 4u : 0u);
+            const uint32_t qf = __shfl(myFlags, wl);
+            RayInst Q;
+            Q.o = mk3(__shfl(R.o.x, wl), __shfl(R.o.y, wl), __shfl(R.o.z, wl));
+            Q.d = mk3(__shfl(R.d.x, wl), __shfl(R.d.y, wl), __shfl(R.d.z, wl));
+            Q.rcp = mk3(__shfl(R.rcp.x, wl), __shfl(R.rcp.y, wl), __shfl(R.rcp.z, wl));
+            Q.exactOnly = (qf & 1u) != 0u;
+            uint32_t cntL = 0, stL = 0, cntR = 0, stR = 0, pushL = COOP_NONE, pushR = COOP_NONE;
+            int delta = 0;
+            if (valid) {
+                delta = -1;
+                const bool dropIt = (REC != 1) && (qf & 4u) && L.best[wl] != ~0ull;      // shadow ray already answered
+                if (!dropIt) {
+                    const float4* wp = reinterpret_cast<const float4*>(A.wide + (item & POOL_NODE_MASK));
+                    const float4 l0 = wp[0], l1 = wp[1], r0 = wp[2], r1 = wp[3];
+                    const uint32_t ld0 = __float_as_uint(l0.w), ld1 = __float_as_uint(l1.w);
+                    const uint32_t rd0 = __float_as_uint(r0.w), rd1 = __float_as_uint(r1.w);
+                    if (ld1 & WIDE_LEAF) { cntL = ld1 & 0x7fffffffu; stL = ld0; }
+                    else if (slab_fast(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z))) pushL = ld0;
+                    if (rd1 & WIDE_LEAF) { cntR = rd1 & 0x7fffffffu; stR = rd0; }
+                    else if (slab_fast(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z))) pushR = rd0;
+                    delta += (pushL != COOP_NONE ? 1 : 0) + (pushR != COOP_NONE ? 1 : 0);
+                }
+            }
+            {   // right children below left ones: the left half of a wide node holds the subtree with the smaller stack need
+                const unsigned long long mR = __ballot(pushR != COOP_NONE), mL = __ballot(pushL != COOP_NONE);
+                const uint32_t nR = (uint32_t)__popcll(mR);
+                if (pushR != COOP_NONE) pool[poolTop + lanes_below(mR)] = (wl << POOL_LANE_SHIFT) | (pushR & POOL_NODE_MASK);
+                if (pushL != COOP_NONE) pool[poolTop + nR + lanes_below(mL)] = (wl << POOL_LANE_SHIFT) | (pushL & POOL_NODE_MASK);
+                poolTop += nR + (uint32_t)__popcll(mL);
+            }
+            if (valid && delta != 0) atomicAdd(&pendN[wl], (uint32_t)delta);
+            const uint32_t tagBits = (wl << COOP_LANE_SHIFT) | (((qf >> 1) & 1u) << COOP_PAR_SHIFT);
+            while (__any((cntL | cntR) != 0u)) {
+                const uint32_t cl = min(cntL, 8u), cr = min(cntR, 8u);
+                coop_enqueue(A, L, lane, tagBits, cl, stL, qHead, qTail, tmin, tmax, R, par, w6);
+                coop_enqueue(A, L, lane, tagBits, cr, stR, qHead, qTail, tmin, tmax, R, par, w6);
+                stL += cl; cntL -= cl; stR += cr; cntR -= cr;
+            }
+            if (qTail - qHead >= 64u) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
+            continue;
+        }
+        // (not reached: with an empty pool one of the two top-level branches above is always taken)
+        if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
+    }
+    pol.retire(st);
+#undef POOL_TPOP
+#undef POOL_START_RAY
+}
+
+} // namespace rdx

@@ -89,12 +89,12 @@ def test_traversal_bit_exact(mods, name):
         assert list(visit) == [c["top_nodes"][rec - 1], c["inst_visits"][rec - 1], c["bot_nodes"][rec - 1], c["tri_tests"][rec - 1]]
         # production kernels: 2 = wave-cooperative (default), 1 = per-lane wide nodes; both use the fast
         # slab test and a free visiting order, and must still land on the reference's exact HitData
-        for kernel in (2, 1):
+        for kernel in (3, 2, 1):
             rd.SetOption("kernel", kernel)
             try:
                 fast = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
             finally:
-                rd.SetOption("kernel", 2)
+                rd.SetOption("kernel", 3)
             assert np.array_equal(ref["hit"], fast["hit"]), kernel
             if rec == 1:        # a shadow ray only reports whether a candidate exists
                 for f in fields:
@@ -392,7 +392,7 @@ def test_full_size_kernels_agree_bitwise(mods, cfg):
     dev = scenes.DeviceScene(s)
     ref = None
     try:
-        for kernel in (0, 2, 1):
+        for kernel in (0, 3, 2, 1):
             rd.SetOption("kernel", kernel)
             dev.set_rtprop(totalSamples=0); dev.clear_scratch()
             img = dev.render().copy()
@@ -405,7 +405,7 @@ def test_full_size_kernels_agree_bitwise(mods, cfg):
                 assert np.array_equal(_bits(ref[0]), _bits(cur[0])), kernel
                 assert np.array_equal(ref[1], cur[1]) and ref[2:] == cur[2:], kernel
     finally:
-        rd.SetOption("kernel", 2)
+        rd.SetOption("kernel", 3)
 
 
 def test_fused_and_split_schedules_identical(mods):
@@ -481,12 +481,12 @@ def test_instanced_grid_and_ragged_batches(mods):
     for n in (0, 1, 63, 64, 65, 1000, 20000):
         for rec in (1, 2):
             ref = ob.trace_batch(blob_o, o[:n], d[:n], 0.001, 1000.0, rec)
-            for kernel in (2, 1, 0):
+            for kernel in (3, 2, 1, 0):
                 rd.SetOption("kernel", kernel)
                 try:
                     got = rd.TraceBatch(dev.topAccelStruct, o[:n], d[:n], 0.001, 1000.0, rec)
                 finally:
-                    rd.SetOption("kernel", 2)
+                    rd.SetOption("kernel", 3)
                 assert got.shape[0] == n and np.array_equal(ref["hit"], got["hit"]), (n, rec, kernel)
                 h = ref["hit"] == 1
                 if rec == 1:

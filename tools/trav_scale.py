@@ -30,4 +30,4 @@ for n in (64, 1024, 16384, 65536, 262144, 1048576, o2.shape[0]):
             rd.TraceBatch(dev.topAccelStruct, o2[:n], d2[:n], 0.001, 1000.0, 1)
             ts.append(rd.GetTraceStats().ms_extend)
         print("%s n=%8d kernel=%d  %.4f ms  (%.3f ns/ray)" % (cfg, n, kernel, min(ts), 1e6 * min(ts) / n), flush=True)
-rd.SetOption("kernel", 2)
+rd.SetOption("kernel", 3)

@@ -27,10 +27,10 @@ bad = 0
 for name, (oo, dd) in (("primary", (o, d)), ("scattered", (o2, d2))):
     for rec in (1, 2):
         r0 = rd.TraceBatch(dev.topAccelStruct, oo, dd, 0.001, 1000.0, rec, reference_order=True)
-        for kernel in (2, 1):
+        for kernel in (3, 2, 1):
             rd.SetOption("kernel", kernel)
             r = rd.TraceBatch(dev.topAccelStruct, oo, dd, 0.001, 1000.0, rec)
-            rd.SetOption("kernel", 2)
+            rd.SetOption("kernel", 3)
             same = np.array_equal(r0["hit"], r["hit"]) if rec == 2 else np.array_equal(r0.view(np.uint8), r.view(np.uint8))
             print("%-9s rec=%d kernel=%d n=%d hits=%d identical=%s" % (name, rec, kernel, oo.shape[0], int(r["hit"].sum()), same), flush=True)
             bad += 0 if same else 1
