@@ -21,18 +21,35 @@
 
 namespace rdx {
 
-#ifndef POOL_EXTRA
-#define POOL_EXTRA 0u                  // pool capacity = 64 * (BLAS stack need + POOL_EXTRA) entries (0: 20 waves / CU on the Sponza-class scene)
+// Pool capacity: 64 * BLAS stack need entries, but no more than lets the wave's LDS stay within 8 KB -- 20 waves per CU
+// (the engine lives on residency, tools/occupancy_probe.sh) -- and no less than an instance step needs to push 64 roots.
+#ifndef POOL_LDS_WORDS
+#define POOL_LDS_WORDS 2048u
 #endif
-__host__ __device__ inline uint32_t pool_cap(uint32_t blasNeed) { return 64u * (blasNeed + POOL_EXTRA) < 128u ? 128u : 64u * (blasNeed + POOL_EXTRA); }
+__host__ __device__ inline uint32_t pool_fixed_words() { return 64u + COOP_QCAP + COOP_RAY_WORDS * 64u + 128u; }
+__host__ __device__ inline uint32_t pool_cap(uint32_t topNeed, uint32_t blasNeed)
+{
+    const uint32_t used = topNeed * 64u + pool_fixed_words();
+    const uint32_t budget = used < POOL_LDS_WORDS ? ((POOL_LDS_WORDS - used) & ~63u) : 0u;
+    uint32_t cap = 64u * (blasNeed ? blasNeed : 1u);
+    if (cap > budget) cap = budget;
+    const uint32_t least = (64u + blasNeed + 3u + 64u + 63u) & ~63u;       // 64 roots + RESERVE + one wide step
+    return cap < least ? least : cap;
+}
 __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32_t blasNeed)
 {
-    return topNeed * 64u + pool_cap(blasNeed) + 64u + COOP_QCAP + COOP_RAY_WORDS * 64u + 128u;
+    return topNeed * 64u + pool_cap(topNeed, blasNeed) + pool_fixed_words();
 }
 
 #define POOL_LANE_SHIFT 26u            // pool item = owning lane << 26 | wide-node index
 #define POOL_NODE_MASK ((1u << POOL_LANE_SHIFT) - 1u)
 #define POOL_INBLAS 0xfffffffeu        // top-level cursor of a lane whose instance is in the pool
+#ifndef POOL_W_TOP
+#define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
+#endif
+#ifndef POOL_W_INST
+#define POOL_W_INST 12
+#endif
 #ifndef POOL_IDLE_MIN
 #define POOL_IDLE_MIN 32               // finished / free lanes a hand-over step waits for (16: +13 %, 24: +4 %, 40-48: +0-3 % frame time)
 #endif
@@ -43,7 +60,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
 {
     static_assert(!Policy::kShades, "the pool engine has no shade step");
     const uint32_t lane = __lane_id();
-    const uint32_t PCAP = pool_cap(A.blasNeed), RESERVE = A.blasNeed + 3u;
+    const uint32_t PCAP = pool_cap(A.topNeed, A.blasNeed), RESERVE = A.blasNeed + 3u;
     uint32_t* tstack = lds + lane;                         // [level * 64]: top-level entries of this lane's ray
     uint32_t* pool = lds + A.topNeed * 64u;
     uint32_t* pendN = pool + PCAP;                         // [64] outstanding pool items of the lane's current instance
@@ -168,7 +185,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         if (qTail - qHead >= 64u) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
 
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------------------
-        if (nTop > 0 && nTop * COOP_W_TOP >= nPool * 4 && nTop * COOP_W_TOP >= nInst * COOP_W_INST) {
+        if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
             if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
             if (isTop && tcur != COOP_NONE) {
                 const float4* np = reinterpret_cast<const float4*>(A.ctnodes + (tcur & IDX_MASK));
@@ -201,7 +218,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             continue;
         }
         // ---- instance entry (radiance.cl:161-169): the BLAS root goes into the pool ----------------------------------
-        if (nInst > 0 && nInst * COOP_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE) {
+        if (nInst > 0 && nInst * POOL_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE) {
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
             if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
             if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }

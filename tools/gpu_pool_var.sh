@@ -6,7 +6,7 @@ run() { for wh in "1920 1080 sample1" "1920 1080 sponza" "680 381 sample1"; do s
     python -c "
 import json; d=json.load(open('gpurun_out/bv.json')); s=d['stage_ms_per_frame']; print('kernel $K $3 $1x$2', d['value'], d['ms_per_step'], 'ext', s['extend'], 'shd', s['shadow'], 'fused', s['fused'])"
   done; }
-export RDX_LIB=$PWD/radiance-ray-tracing_amd/librdx.so; K=2; echo "=== default, kernel 2"; run
+true
 for lib in radiance-ray-tracing_amd/librdx.so $(ls radiance-ray-tracing_amd/librdx_*.so 2>/dev/null); do
   export RDX_LIB=$PWD/$lib; K=3; echo "=== $lib"; run
 done

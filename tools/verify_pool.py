@@ -32,16 +32,15 @@ for name, s in cfgs:
             ref = rd.TraceBatch(dev.topAccelStruct, o[:n], d[:n], 0.001, 1000.0, rec, reference_order=True)
             rd.SetOption("kernel", 3)
             got = rd.TraceBatch(dev.topAccelStruct, o[:n], d[:n], 0.001, 1000.0, rec)
-            rd.SetOption("kernel", 3)
             same = np.array_equal(ref["hit"], got["hit"]) if rec == 2 else np.array_equal(ref.view(np.uint8), got.view(np.uint8))
             if not same:
                 bad += 1
                 print("MISMATCH", name, n, rec, int((ref["hit"] != got["hit"]).sum()), flush=True)
-    # frames: pool engine vs default engine, bit for bit
+    # frames: pool engine (3) vs per-lane-stack engine (2), bit for bit
+    rd.SetOption("kernel", 2)
     dev.render(); a = dev.read_scratch().copy(); sa = rd.GetTraceStats()
     rd.SetOption("kernel", 3)
     dev.set_rtprop(totalSamples=0); dev.clear_scratch(); dev.render(); b = dev.read_scratch().copy(); sb = rd.GetTraceStats()
-    rd.SetOption("kernel", 3)
     same = np.array_equal(a.view(np.uint32), b.view(np.uint32)) and sa.rays_bounce == sb.rays_bounce and sa.rays_shadow == sb.rays_shadow
     print("%-7s batches ok=%s frame identical=%s (%.2f ms vs %.2f ms)" % (name, bad == 0, same, sa.ms_total, sb.ms_total), flush=True)
     bad += 0 if same else 1
