@@ -8,7 +8,8 @@ workload, scene and accumulators already resident in HBM.  N > 1: one process pe
 while rendering, one RGBA8 gather to rank 0 at frame end -- inside the timed region.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline      dominant kernel (k_extend, closest-hit BVH walk): algorithmic bytes of the launches
+  roofline      dominant kernel (the traversal launches: k_fused_pool = shadow rays of bounce d + closest-hit rays of
+                bounce d+1 per launch; k_extend_pool when launches are not fused): algorithmic bytes of the launches
                 in the timed region / their HIP-event time, against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (a port of the reference algorithm) on a bounded pixel sample of the
                 same workload, on this box's host cores
@@ -61,6 +62,9 @@ def algorithmic_bytes(top, inst, bot, tri, rays):
     return 16 * rays + 48 * top + 96 * inst + 48 * bot + 64 * tri
 
 
+ENGINE = "pool"          # suffix of the traversal kernels' names: k_fused_pool (library default, kernel option 3) / k_fused_coop (2)
+
+
 def traversal_roofline(acc, visits, steps, depth):
     """(kernel name, algorithmic bytes of its launches per frame, seconds of those launches over the timed region,
     launches) of the dominant traversal kernel"""
@@ -80,12 +84,12 @@ def traversal_roofline(acc, visits, steps, depth):
         def bytes_of(d, cls):
             v = prof[d, cls]
             return algorithmic_bytes(v[0], v[1], v[2], v[3], cnt[d] if cls == 0 else cnt[d + 1])
-        return ("k_fused_coop", sum(bytes_of(d, 1) + bytes_of(d + 1, 0) for d in range(D - 1)), acc["ms_fused"] * 1e-3,
+        return ("k_fused_" + ENGINE, sum(bytes_of(d, 1) + bytes_of(d + 1, 0) for d in range(D - 1)), acc["ms_fused"] * 1e-3,
                 max(1, steps * (D - 1)))
     rays = (acc["primary"] + acc["bounce"]) / steps
     b = algorithmic_bytes(visits["visit_top_nodes"][0], visits["visit_instances"][0], visits["visit_bot_nodes"][0],
                           visits["visit_triangles"][0], rays)
-    return ("k_extend", b, acc["ms_extend"] * 1e-3, max(1, acc["launches_extend"]))
+    return ("k_extend_" + ENGINE, b, acc["ms_extend"] * 1e-3, max(1, acc["launches_extend"]))
 
 
 def cpu_baseline(scene, budget_s=20.0):
@@ -172,6 +176,8 @@ def main():
         rd.SetOption("pipeline", args.pipeline)
     if args.kernel >= 0:
         rd.SetOption("kernel", args.kernel)
+        global ENGINE
+        ENGINE = "pool" if args.kernel == 3 else "coop"
 
     def run_workload(key, steps, warmup, want_roofline):
         cfg, label = WORKLOADS[key]
@@ -249,7 +255,7 @@ def main():
         return
     steps = args.steps
     ms_per_step = 1e3 * dt / steps
-    # roofline of the dominant kernel: k_extend (all launches of the timed region)
+    # roofline of the dominant kernel: the traversal launches of the timed region
     rays_extend_per_frame = (acc["primary"] + acc["bounce"]) / steps
     bytes_extend_frame = algorithmic_bytes(visits["visit_top_nodes"][0], visits["visit_instances"][0],
                                            visits["visit_bot_nodes"][0], visits["visit_triangles"][0], rays_extend_per_frame)
@@ -284,14 +290,14 @@ def main():
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             # HBM bytes per launch from the committed PMC passes of the 1-GPU, full-frame run of this workload (a rank of
             # an N-GPU run launches on 1/N of the frame: no PMC figure for that)
-            "traffic": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[0]
+            "traffic": (pmc_traffic("rdx::" + kernel_name, args.workload) or (None, None))[0]
                        if world == 1 and (args.width, args.height, args.spp, args.depth) == (1920, 1080, 4, 8) else None,
-            "traffic_source": (pmc_traffic("rdx::" + kernel_name + ("_coop" if kernel_name == "k_extend" else ""), args.workload) or (None, None))[1]
+            "traffic_source": (pmc_traffic("rdx::" + kernel_name, args.workload) or (None, None))[1]
                               if world == 1 and (args.width, args.height, args.spp, args.depth) == (1920, 1080, 4, 8) else None,
             "algorithmic_bytes_per_launch": int(roof_bytes * steps / launches),
             "avg_launch_ms": round(1e3 * trav_s / launches, 4),
             "launches": launches,
-            "note": "achieved = reference-walk bytes (16/ray + 48/node + 96/instance visit + 64/triangle) of the k_extend "
+            "note": "achieved = reference-walk bytes (16/ray + 48/node + 96/instance visit + 64/triangle) of the traversal "
                     "launches (fused: shadow rays of bounce d + closest-hit rays of bounce d+1 per launch) in the timed region / "
                     "their HIP-event time; traffic (PMC) see profiles/",
         },
