@@ -99,6 +99,10 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
 #if COOP_WATCHDOG
     uint32_t iter = 0;
 #endif
+#ifdef COOP_STATS
+    uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // as traverse_coop.h; kind 6 = pool step
+    uint32_t stState[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
 #if COOP_WATCHDOG
         iter = __builtin_amdgcn_readfirstlane(iter + 1u);
@@ -117,10 +121,15 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         const int nPool = (int)min(64u, poolTop);
         const bool workAny = (nTop | nInst) != 0 || poolTop != 0u;
         const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
+#ifdef COOP_STATS
+        stState[0] += __popcll(__ballot(tcur == POOL_INBLAS)); stState[1] += nTop; stState[2] += nInst;
+        stState[4] += __popcll(__ballot(finishing && !done)); stState[5] += __popcll(doneMask); stState[6] += __popcll(freeMask); stState[7] += 64;
+#endif
 
         // ---- hand-over: finished rays are written out, free lanes take new rays -----------------------------------
         // (the pool usually holds 64+ items, so -- unlike traverse_coop.h -- the trigger is an absolute number of idle lanes)
         if (nIdle > 0 && (nIdle >= POOL_IDLE_MIN || !workAny)) {
+            COOP_STAT(0, nIdle);
             if (done) {
                 Best B;
                 B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
@@ -186,6 +195,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
 
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------------------
         if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
+            COOP_STAT(4, nTop);
             if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
             if (isTop && tcur != COOP_NONE) {
                 const float4* np = reinterpret_cast<const float4*>(A.ctnodes + (tcur & IDX_MASK));
@@ -221,6 +231,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         if (nInst > 0 && nInst * POOL_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE) {
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
             if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            COOP_STAT(5, __popcll(__ballot(ready)));
             if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
             uint32_t cntE = 0, stE = 0, rootNode = COOP_NONE;
             if (ready && tcur != COOP_NONE) {
@@ -278,6 +289,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         if (poolTop != 0u) {
             const uint32_t freeE = PCAP - poolTop;
             const uint32_t npop = min(min(64u, poolTop), freeE > RESERVE ? freeE - RESERVE : 1u);
+            COOP_STAT(6, npop);
             const bool valid = lane < npop;
             const uint32_t item = valid ? pool[poolTop - 1u - lane] : (lane << POOL_LANE_SHIFT);
             poolTop -= npop;
@@ -328,6 +340,10 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         // (not reached: with an empty pool one of the two top-level branches above is always taken)
         if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     }
+#ifdef COOP_STATS
+    if (lane < 8u) atomicAdd(&g_coop_state[lane], (unsigned long long)stState[lane]);
+    if (lane < 7u) { atomicAdd(&g_coop_stats[lane], (unsigned long long)statN[lane]); atomicAdd(&g_coop_stats[8u + lane], (unsigned long long)statL[lane]); }
+#endif
     pol.retire(st);
 #undef POOL_TPOP
 #undef POOL_START_RAY

@@ -8,7 +8,7 @@ import numpy as np
 import rrt_amd
 from radiance_ray_tracing_amd import rd, scenes, _lib
 
-KINDS = ["finish/refill", "shade", "steal", "leaf item", "top", "instance", "node", "test"]
+KINDS = ["finish/refill", "shade", "steal", "leaf item", "top", "instance", "node / pool", "test"]
 L = _lib.lib()
 fn = L.rdx_debug_coop_stats
 fn.restype = ctypes.c_int
@@ -25,7 +25,7 @@ for cfg, w, h in (("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_co
     rays = st.rays_primary + st.rays_bounce + st.rays_shadow
     print("%s %dx%d: %d rays, %.0f wave-steps (%.1f per 64 rays)" % (cfg, w, h, rays, n.sum(), n.sum() / (rays / 64)))
     stt = np.array(out[16:24], np.float64)
-    names = ["node", "top", "instance", "leaf", "finishing (tests pending)", "done (waits for hand-over)", "free"]
+    names = ["node (pool engine: instance in the pool)", "top", "instance", "leaf", "finishing (tests pending)", "done (waits for hand-over)", "free"]
     print("  lane states per iteration: " + ", ".join("%s %.1f" % (names[k], 64 * stt[k] / stt[7]) for k in range(7))
           + ", other %.1f" % (64 - 64 * stt[:7].sum() / stt[7]))
     for k in range(8):
