@@ -354,7 +354,7 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->bnodes, dB));
     HIP_OK(up(ac->tris, dTri));
     HIP_OK(up(ac->wide, dW));
-    ac->coopOK = coopOK && dTri.size() < (1u << 26);
+    ac->coopOK = coopOK && dTri.size() < (1u << 26) && dW.size() < (1u << 26);      // (pool items carry a 26-bit wide-node index)
     if (std::getenv("RDX_VERBOSE"))
         std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u = top %u + BLAS %u)\n",
                      nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed, ac->topNeed, ac->blasNeed);
