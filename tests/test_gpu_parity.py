@@ -557,3 +557,15 @@ def test_cpp_scene_loader_sample(mods, tmp_path):
     assert os.path.exists(path + ".cache") and os.path.exists(path + ".cache.meta")
     assert outs[0] == outs[1]
     assert np.frombuffer(outs[0][len(b"P6\n96 54\n255\n"):], np.uint8).std() > 10
+
+
+def test_fuzz_random_scenes(mods):
+    """tools/fuzz_parity.py, 12 seeds: random meshes (incl. stacks of coincident triangles -> leaves of more than 8
+    triangles), up to 70 instances with random affine transforms and shared BLASes, rays from everywhere: every
+    production kernel returns the reference-order kernel's HitData bit for bit (that kernel is pinned to the oracle by
+    the tests above)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    assert fz.run(12, first_seed=500, verbose=False) == 0
