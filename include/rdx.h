@@ -128,6 +128,9 @@ int         rdx_pack_tiles(rdx_buffer image, rdx_buffer packed, uint32_t width, 
                            uint32_t elem_size, uint32_t rank, uint32_t world);
 int         rdx_unpack_tiles(rdx_buffer packed, rdx_buffer image, uint32_t width, uint32_t height,
                              uint32_t elem_size, uint32_t rank, uint32_t world);
+/* the same for the packed buffers of ranks first_rank .. first_rank + n - 1 in one call (one synchronisation) */
+int         rdx_unpack_tiles_multi(const rdx_buffer* packed, uint32_t first_rank, uint32_t n, rdx_buffer image,
+                                   uint32_t width, uint32_t height, uint32_t elem_size, uint32_t world);
 uint32_t    rdx_shard_pixel_count(uint32_t width, uint32_t height, uint32_t rank, uint32_t world);
 
 /* Statistics of the last rdx_trace_rays call. */

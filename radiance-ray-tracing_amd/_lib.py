@@ -82,6 +82,7 @@ SIGNATURES = {
     "rdx_set_shard": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rdx_pack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rdx_unpack_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rdx_unpack_tiles_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rdx_shard_pixel_count": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rdx_get_trace_stats": (C.c_int, [C.POINTER(rdx_trace_stats)]),
     "rdx_get_visit_profile": (C.c_int, [C.c_void_p, C.c_uint32]),

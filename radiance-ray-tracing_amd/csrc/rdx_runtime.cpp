@@ -838,6 +838,31 @@ extern "C" int rdx_pack_tiles(rdx_buffer image, rdx_buffer packed, uint32_t w, u
 { return pack_impl(image, packed, w, h, elem, rank, world, false); }
 extern "C" int rdx_unpack_tiles(rdx_buffer packed, rdx_buffer image, uint32_t w, uint32_t h, uint32_t elem, uint32_t rank, uint32_t world)
 { return pack_impl(image, packed, w, h, elem, rank, world, true); }
+// the gathering rank's side of a frame: the packed buffers of ranks first_rank .. first_rank + n - 1 go into the image with
+// ONE synchronisation at the end (a call per rank costs a launch + a stream synchronise each: 7 of them per frame at 8 GPUs)
+extern "C" int rdx_unpack_tiles_multi(const rdx_buffer* packed, uint32_t first_rank, uint32_t n, rdx_buffer image, uint32_t w, uint32_t h,
+                                      uint32_t elem, uint32_t world)
+{
+    if (!packed || !image || !known_buffer(image)) return fail("unpack_tiles_multi: invalid buffer");
+    if (elem % 4 || elem == 0) return fail("unpack_tiles_multi: element size must be a multiple of 4");
+    if ((size_t)w * h * elem > image->size) return fail("unpack_tiles_multi: image buffer too small");
+    const uint32_t tilesX = (w + g.tileW - 1) / g.tileW, tilesY = (h + g.tileH - 1) / g.tileH, nT = tilesX * tilesY;
+    for (uint32_t k = 0; k < n; ++k) {          // validate everything before anything is launched
+        const uint32_t rank = first_rank + k;
+        if (rank >= world || !packed[k] || !known_buffer(packed[k])) return fail("unpack_tiles_multi: invalid packed buffer %u", k);
+        const uint32_t owned = nT > rank ? (nT - rank + world - 1) / world : 0;
+        if ((size_t)owned * g.tileW * g.tileH * elem > packed[k]->size) return fail("unpack_tiles_multi: packed buffer %u too small", k);
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t rank = first_rank + k;
+        launch_pack_tiles(g.stream, static_cast<uint8_t*>(image->dptr), static_cast<uint8_t*>(packed[k]->dptr), w, h, elem,
+                          g.tileW, g.tileH, rank, world, true);
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(g.stream));
+    image->version++;
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // TraceRays

@@ -131,6 +131,7 @@ class FrameSharder:
         gather_to_root(self.packed, self.world, 0, self.recv)
         if self.rank == 0:
             torch.cuda.synchronize()
-            for r in range(1, self.world):
-                if L.rdx_unpack_tiles(self.recv_bufs[r].handle, image_buffer.handle, self.width, self.height, 4, r, self.world):
-                    raise rd.RadianceError(_lib.last_error())
+            import ctypes as C
+            arr = (C.c_void_p * (self.world - 1))(*[self.recv_bufs[r].handle for r in range(1, self.world)])
+            if L.rdx_unpack_tiles_multi(arr, 1, self.world - 1, image_buffer.handle, self.width, self.height, 4, self.world):
+                raise rd.RadianceError(_lib.last_error())

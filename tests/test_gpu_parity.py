@@ -258,6 +258,8 @@ def test_tile_sharding_bit_identical(mods):
     W, H, world = 100, 60, 3
     merged = rd.CreateBuffer(dev.plt, W * H * 16)
     merged_img = rd.CreateBuffer(dev.plt, W * H * 4)
+    merged_multi = rd.CreateBuffer(dev.plt, W * H * 4)
+    packed_imgs = []
     try:
         for r in range(world):
             rd.SetShard(r, world, 16, 16)
@@ -274,12 +276,19 @@ def test_tile_sharding_bit_identical(mods):
             assert L.rdx_unpack_tiles(packed.handle, merged.handle, W, H, 16, r, world) == 0
             assert L.rdx_pack_tiles(dev.rdImage.handle, packed8.handle, W, H, 4, r, world) == 0
             assert L.rdx_unpack_tiles(packed8.handle, merged_img.handle, W, H, 4, r, world) == 0
+            packed_imgs.append(packed8)
+        # the gathering rank's one-call variant: every rank's packed buffer in one go
+        import ctypes as C
+        arr = (C.c_void_p * world)(*[p.handle for p in packed_imgs])
+        assert L.rdx_unpack_tiles_multi(arr, 0, world, merged_multi.handle, W, H, 4, world) == 0
+        assert L.rdx_unpack_tiles_multi(arr, 1, world, merged_multi.handle, W, H, 4, world) != 0      # rank out of range
     finally:
         rd.SetShard(0, 1, 64, 64)
     got = np.empty(W * H * 4, np.float32)
     rd.ReadBuffer(dev.plt, merged, got.nbytes, got.view(np.uint8))
     assert np.array_equal(_bits(got[np.arange(W * H * 4) % 4 != 3]), _bits(full.reshape(-1)[np.arange(W * H * 4) % 4 != 3]))
     assert np.array_equal(rd.ReadBuffer(dev.plt, merged_img, W * H * 4), full_img)
+    assert np.array_equal(rd.ReadBuffer(dev.plt, merged_multi, W * H * 4), full_img)
 
 
 def test_tlas_cache_file_roundtrip(mods, tmp_path):
