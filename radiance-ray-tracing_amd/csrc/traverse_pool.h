@@ -44,6 +44,9 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
 #define POOL_LANE_SHIFT 26u            // pool item = owning lane << 26 | wide-node index
 #define POOL_NODE_MASK ((1u << POOL_LANE_SHIFT) - 1u)
 #define POOL_INBLAS 0xfffffffeu        // top-level cursor of a lane whose instance is in the pool
+#ifndef POOL_TEST_MIN
+#define POOL_TEST_MIN 48u              // queued triangle tests a test step waits for (32-64: flat within 1.5 %; 96-128: +2-5 %)
+#endif
 #ifndef POOL_W_TOP
 #define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
 #endif
@@ -191,7 +194,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             if (__ballot(rayIdx != COOP_NONE) == 0ull) break;      // exhausted, every lane free, queue and pool empty
             continue;                                              // lanes still finishing: next round hands them over
         }
-        if (qTail - qHead >= 64u) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+        if (qTail - qHead >= POOL_TEST_MIN) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
 
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------------------
         if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
@@ -334,7 +337,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 coop_enqueue(A, L, lane, tagBits, cr, stR, qHead, qTail, tmin, tmax, R, par, w6);
                 stL += cl; cntL -= cl; stR += cr; cntR -= cr;
             }
-            if (qTail - qHead >= 64u) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
+            if (qTail - qHead >= POOL_TEST_MIN) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
             continue;
         }
         // (not reached: with an empty pool one of the two top-level branches above is always taken)
