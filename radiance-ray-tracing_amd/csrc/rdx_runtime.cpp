@@ -57,6 +57,11 @@ struct rdx_buffer_s {
     std::vector<uint8_t> shadow;           // host copy of a TLAS blob (valid iff shadowVersion == version)
     uint64_t shadowVersion = ~0ull;
     std::unique_ptr<AccelCache> accel;
+    // small parameter buffers (RTProp, camera): a host mirror kept current by the write path, so that TraceRays does
+    // not read them back from the device every frame.  Valid only for library-owned buffers whose every byte has been
+    // written through the API since creation (device code never writes them); wrapped memory is never mirrored.
+    std::vector<uint8_t> mirror;
+    bool mirrorValid = false;
 };
 struct rdx_blas_s { std::unique_ptr<Blas> blas; };
 struct rdx_shader_s { std::string name; bool hasRaygen = false; };
@@ -590,6 +595,10 @@ extern "C" int rdx_buffer_write(rdx_buffer b, size_t offset, size_t size, const 
     if (offset + size > b->size) return fail("WriteBuffer: range [%zu, %zu) exceeds buffer size %zu", offset, offset + size, b->size);
     if (size) HIP_OK(hipMemcpy(static_cast<uint8_t*>(b->dptr) + offset, src, size, hipMemcpyHostToDevice));
     b->version++;
+    if (b->owned && b->size <= 256) {
+        if (offset == 0 && size == b->size) { b->mirror.assign(static_cast<const uint8_t*>(src), static_cast<const uint8_t*>(src) + size); b->mirrorValid = true; }
+        else if (b->mirrorValid && size) std::memcpy(b->mirror.data() + offset, src, size);
+    }
     return 0;
 }
 
@@ -924,8 +933,10 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
 
     // per-frame constants live in device buffers the caller may have rewritten (sample1.cpp:480-490)
     RayTraceProperties rt; PhysicalCamera cam;
-    HIP_OK(hipMemcpy(&rt, bRT->dptr, sizeof rt, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(&cam, bCam->dptr, sizeof cam, hipMemcpyDeviceToHost));
+    if (bRT->mirrorValid && bRT->mirror.size() >= sizeof rt) std::memcpy(&rt, bRT->mirror.data(), sizeof rt);
+    else HIP_OK(hipMemcpy(&rt, bRT->dptr, sizeof rt, hipMemcpyDeviceToHost));
+    if (bCam->mirrorValid && bCam->mirror.size() >= sizeof cam) std::memcpy(&cam, bCam->mirror.data(), sizeof cam);
+    else HIP_OK(hipMemcpy(&cam, bCam->dptr, sizeof cam, hipMemcpyDeviceToHost));
     CameraArgs C;
     camera_args(cam, C);
     if ((uint32_t)cam.widthPixel == 0) return fail("TraceRays: camera widthPixel is 0");
