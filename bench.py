@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=-1, help="-1 auto, 0/1: shadow(d)+extend(d+1) in one launch")
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 library default, 0 staged wavefront, 1 whole paths in one persistent launch")
     ap.add_argument("--kernel", type=int, default=-1, help="-1 library default; 2 cooperative, 3 cooperative with a shared node pool, 1 / 0 per-lane")
+    ap.add_argument("--top-flat", type=int, default=-1, help="-1 library default; 0/1: evaluate small top-level trees all at once (pool engine)")
     ap.add_argument("--also", default="", help="comma list of extra workloads to time (reported under 'also')")
     args = ap.parse_args()
 
@@ -174,6 +175,8 @@ def main():
     rd.SetOption("fuse", args.fuse)
     if args.pipeline >= 0:
         rd.SetOption("pipeline", args.pipeline)
+    if args.top_flat >= 0:
+        rd.SetOption("top_flat", args.top_flat)
     if args.kernel >= 0:
         rd.SetOption("kernel", args.kernel)
         global ENGINE

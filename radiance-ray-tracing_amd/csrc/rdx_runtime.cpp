@@ -36,6 +36,8 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     uint32_t stackNeed = 1;            // per-lane kernels (reference order: left child followed, right child pushed)
     uint32_t coopNeed = 1;             // wave-cooperative kernel (leaf children are never pushed, smaller subtree first)
     uint32_t topNeed = 1, blasNeed = 0; // its two parts: top-level entries of one ray / entries inside one BLAS (pool engine)
+    uint32_t topFlat = 0, topFlatNeed = 1; // pool engine: number of top-level nodes if they are few enough (<= 64) to be evaluated
+                                        // all at once per ray instead of walked, and the instance-mask entries that can then pile up
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
     void release()
     {
@@ -108,6 +110,7 @@ struct Context {
     // options
     int64_t chunkPaths = 16ll << 20;
     bool countVisits = false, profiling = false;
+    int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
     rdx_trace_stats stats{};
@@ -344,6 +347,12 @@ int derive_accel(rdx_buffer_s* tb)
     // oversized leaves are cut into 8-triangle work items: all but the first piece of each child are pushed
     ac->coopNeed = std::max(1u, needC[0]) + 1u + 2u * ((std::max(maxLeafTris, 1u) + 7u) / 8u - 1u);
     ac->topNeed = std::max(1u, needTopOnly[0]) + 1u;
+    {
+        uint32_t masks = 0;
+        for (uint32_t i = 0; i < nTop; ++i) if (tnodes[i].w0 & LEAF_BIT) masks += ((tnodes[i].w0 & 0x7fffffffu) + 15u) / 16u;
+        ac->topFlat = (nTop <= 64 && masks <= 24) ? nTop : 0u;
+        ac->topFlatNeed = masks + 1u;
+    }
     ac->blasNeed = maxBlasCoop;
     if (ac->stackNeed > 2560) return fail("BVH too deep for the LDS traversal stack (%u entries)", ac->stackNeed);
     auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
@@ -378,6 +387,8 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.stackNeed = tb->accel->stackNeed;
     v.coopNeed = tb->accel->coopNeed;
     v.topNeed = tb->accel->topNeed; v.blasNeed = tb->accel->blasNeed;
+    v.topFlat = g.topFlat ? tb->accel->topFlat : 0u;
+    if (v.topFlat) v.topNeed = std::max(v.topNeed, tb->accel->topFlatNeed);
     return v;
 }
 
@@ -886,6 +897,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "overlap")) { if (value < 0 || value > 1) return fail("overlap must be 0 or 1"); g.overlap = (int)value; return 0; }
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
+    if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
 }

@@ -200,6 +200,44 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
             COOP_STAT(4, nTop);
             if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
+            if (A.topFlat != 0u) {
+                // Small top-level tree (<= 64 nodes): no walk.  Every node is looked at once, in index order (parents come
+                // before their children, DFS pre-order), by all lanes of the step together -- the node is the same for all
+                // of them, so its box comes through scalar loads and nothing is fetched along a dependent chain.  `reach`
+                // says which nodes the reference's walk arrives at: the root, and the children of every reached inner node
+                // whose box the ray hits (same decision rule); reached leaves file their instances (after the pre-test) as
+                // mask entries.  Same visit set, 1 step instead of one per visited node.
+                if (isTop && tcur != COOP_NONE) {
+                    RayInst W;
+                    W.o = o; W.d = d;
+                    W.rcp = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                    const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+                    const float amax_ = fmaxf(fmaxf(fabsf(W.rcp.x), fabsf(W.rcp.y)), fabsf(W.rcp.z));
+                    W.exactOnly = !(amin_ > 1e-20f) || !(amax_ < 1e20f);
+                    const float oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+                    const bool preOK = !W.exactOnly && (oMax < 1e20f);
+                    unsigned long long reach = 1ull;
+                    for (uint32_t i = 0; i < A.topFlat; ++i) {
+                        const float4* np = reinterpret_cast<const float4*>(A.tnodes + i);
+                        const uint4 w = *reinterpret_cast<const uint4*>(np + 2);
+                        const bool r = ((reach >> i) & 1ull) != 0ull;
+                        if (!(w.x & LEAF_BIT)) {
+                            const float4 bmin = np[0], bmax = np[1];
+                            if (r && slab_fast(W, mk3(bmin.x, bmin.y, bmin.z), mk3(bmax.x, bmax.y, bmax.z))) reach |= (1ull << w.x) | (1ull << w.y);
+                        } else if (w.z == TYPE_INST && r) {
+                            const uint32_t count = w.x & 0x7fffffffu;
+                            for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
+                                uint32_t m16 = 0;
+                                for (uint32_t k = 0; k < min(16u, count - b0); ++k)
+                                    if (coop_inst_pretest(A.insts[w.y + b0 + k], o, W.rcp, oMax, preOK)) m16 |= 1u << k;
+                                if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                            }
+                        }
+                    }
+                    POOL_TPOP();
+                }
+                continue;
+            }
             if (isTop && tcur != COOP_NONE) {
                 const float4* np = reinterpret_cast<const float4*>(A.ctnodes + (tcur & IDX_MASK));
                 const float4 bmin = np[0], bmax = np[1];
