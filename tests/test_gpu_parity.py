@@ -578,3 +578,41 @@ def test_fuzz_random_scenes(mods):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     assert fz.run(12, first_seed=500, verbose=False) == 0
+
+
+def test_large_and_walked_top_level_trees(mods):
+    """the pool kernel evaluates top-level trees of <= 64 nodes all at once and walks larger ones: a 343-instance grid
+    (more than 64 top-level nodes -> walked) and the same kernel with `top_flat` off on a 27-instance grid (walked by
+    option) both agree with the reference-order kernel bit for bit, closest hit and any hit"""
+    rd, scenes = mods
+    for side, flat in ((7, 1), (3, 0), (3, 1)):
+        s = scenes.Scene("grid%d" % side)
+        ball = s.add_mesh(scenes.icosphere(1, 0.3))
+        cube = s.add_mesh(scenes.box([-0.25, -0.25, -0.25], [0.25, 0.25, 0.25]))
+        s.materials = [scenes.material((0.7, 0.7, 0.7), 0.0, 0.5)]
+        k = 0
+        for ix in range(side):
+            for iy in range(side):
+                for iz in range(side):
+                    tf = scenes.translate(0.9 * (ix - side // 2), 0.9 * (iy - side // 2), 0.9 * (iz - side // 2)) @ scenes.rotate_y(7.0 * k)
+                    s.add_instance(ball if k % 3 else cube, tf, 0)
+                    k += 1
+        s.camera = scenes.blender_camera(64, 48, 0.05, 0.036, 9.0, 0.0, (0.5, 9.0, 1.0), (-96.0, 180.0, 0.0))
+        s.sceneProps = scenes.blender_dir_light(-45.0, 20.0, 5.0)
+        s.rtprop = scenes._rtprop(0, 1, 2)
+        dev = scenes.DeviceScene(s)
+        rng = np.random.default_rng(side)
+        n = 8000
+        o = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+        d = (rng.uniform(-2, 2, (n, 3)).astype(np.float32) - o); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        try:
+            rd.SetOption("top_flat", flat)
+            for rec in (1, 2):
+                ref = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, reference_order=True)
+                got = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+                assert np.array_equal(ref["hit"], got["hit"]), (side, flat, rec)
+                if rec == 1:
+                    assert np.array_equal(_bits(ref), _bits(got)), (side, flat)
+                assert ref["hit"].sum() > 1000
+        finally:
+            rd.SetOption("top_flat", 1)
