@@ -161,7 +161,8 @@ int         rdx_set_profiling(int on);
  * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
  * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
  * cross-checks), "top_flat" (1 (default) / 0: the pool kernel evaluates a top-level tree of <= 64 nodes all at once per
- * ray instead of walking it), "pipeline" (0 = staged
+ * ray instead of walking it), "inline_leaf_roots" (1 (default) / 0: ... and tests the triangles of single-leaf BLASes
+ * right there), "pipeline" (0 = staged
  * wavefront: one launch per stage per bounce (default); 1 = whole paths -- camera ray to path end -- in one
  * persistent cooperative launch per sample chunk), "fuse" (1 / -1 = on (default), 0 = off:
  * trace the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch, which

@@ -797,22 +797,25 @@ k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
 }
 
 // ---- the same three launches on the shared-node-pool engine (traverse_pool.h, `kernel` option 3) ------------------------
+template <bool INL>
 __global__ void COOP_BOUNDS
 k_extend_pool(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
 {
     ExtendPolicy pol{A, ps};
-    traverse_pool<1>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<1, INL>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
+template <bool INL>
 __global__ void COOP_BOUNDS
 k_shadow_pool(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
               uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
     const float* ld = sc.scene->lights[0].direction;
     ShadowPolicy pol{A, ps, normalize3(mk3(-ld[0], -ld[1], -ld[2])), lastBounce, nPixels, sampleBase};
-    traverse_pool<2>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<2, INL>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
+template <bool INL>
 __global__ void COOP_BOUNDS
 k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
              uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
@@ -821,7 +824,7 @@ k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
     const uint32_t m = *mPtr;
     FusedPolicy pol{ShadowPolicy{A, psShadow, normalize3(mk3(-ld[0], -ld[1], -ld[2])), 0u, nPixels, sampleBase},
                     ExtendPolicy{A, psExtend}, m};
-    traverse_pool<3>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<3, INL>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -969,13 +972,13 @@ k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __rest
     traverse_coop<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
-template <int REC>
+template <int REC, bool INL>
 __global__ void COOP_BOUNDS
 k_trace_batch_pool(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
                    float tmin, float tmax, rdx_hit* __restrict__ out)
 {
     BatchPolicy pol{A, o, d, out};
-    traverse_pool<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<REC, INL>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1119,7 +1122,8 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
     if (!nMax) return;
     if (!visit && av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
-        hipLaunchKernelGGL(k_extend_pool, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
+        if (av.leafRoots) hipLaunchKernelGGL(k_extend_pool<true>, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
+        else hipLaunchKernelGGL(k_extend_pool<false>, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
         return;
     }
     if (!visit && av.kernel == 2) {
@@ -1149,8 +1153,10 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
     if (!nMax) return;
     if (!visit && av.kernel == 3) {
         size_t ldsc; const uint32_t thc = pool_threads(av, ldsc);
-        hipLaunchKernelGGL(k_shadow_pool, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
-                           lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
+        if (av.leafRoots) hipLaunchKernelGGL(k_shadow_pool<true>, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
+                                             lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
+        else hipLaunchKernelGGL(k_shadow_pool<false>, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
+                                lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
         return;
     }
     if (!visit && av.kernel == 2) {
@@ -1174,8 +1180,10 @@ void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
     if (!mMax) return;
     if (av.kernel == 3) {
         size_t ldsp; const uint32_t thp = pool_threads(av, ldsp);
-        hipLaunchKernelGGL(k_fused_pool, dim3(coop_blocks(2u * mMax, thp, ldsp)), dim3(thp), ldsp, st, av, sc, psShadow, psExtend, mPtr,
-                           counter, nPixels, sampleBase, tmin, tmax);
+        if (av.leafRoots) hipLaunchKernelGGL(k_fused_pool<true>, dim3(coop_blocks(2u * mMax, thp, ldsp)), dim3(thp), ldsp, st, av, sc, psShadow, psExtend, mPtr,
+                                             counter, nPixels, sampleBase, tmin, tmax);
+        else hipLaunchKernelGGL(k_fused_pool<false>, dim3(coop_blocks(2u * mMax, thp, ldsp)), dim3(thp), ldsp, st, av, sc, psShadow, psExtend, mPtr,
+                                counter, nPixels, sampleBase, tmin, tmax);
         return;
     }
     size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
@@ -1227,8 +1235,13 @@ void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, con
     if (!visit && mode == 0 && av.kernel == 3) {
         size_t ldsp; const uint32_t thp = pool_threads(av, ldsp);
         const dim3 gp(coop_blocks(n, thp, ldsp));
-        if (rec == 2) hipLaunchKernelGGL(k_trace_batch_pool<2>, gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
-        else hipLaunchKernelGGL(k_trace_batch_pool<1>, gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
+        if (av.leafRoots) {
+            if (rec == 2) hipLaunchKernelGGL((k_trace_batch_pool<2, true>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
+            else hipLaunchKernelGGL((k_trace_batch_pool<1, true>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
+        } else {
+            if (rec == 2) hipLaunchKernelGGL((k_trace_batch_pool<2, false>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
+            else hipLaunchKernelGGL((k_trace_batch_pool<1, false>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
+        }
         return;
     }
     if (!visit && mode == 0 && av.kernel == 2) {

@@ -36,6 +36,7 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     uint32_t stackNeed = 1;            // per-lane kernels (reference order: left child followed, right child pushed)
     uint32_t coopNeed = 1;             // wave-cooperative kernel (leaf children are never pushed, smaller subtree first)
     uint32_t topNeed = 1, blasNeed = 0; // its two parts: top-level entries of one ray / entries inside one BLAS (pool engine)
+    bool leafRoots = false;             // some instance's BLAS is a single leaf of <= 8 triangles
     uint32_t topFlat = 0, topFlatNeed = 1; // pool engine: number of top-level nodes if they are few enough (<= 64) to be evaluated
                                         // all at once per ray instead of walked, and the instance-mask entries that can then pile up
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
@@ -110,6 +111,7 @@ struct Context {
     // options
     int64_t chunkPaths = 16ll << 20;
     bool countVisits = false, profiling = false;
+    int inlineLeafRoots = 1;                // pool engine: single-leaf BLASes handled in the flat top-level step (option "inline_leaf_roots")
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
@@ -351,6 +353,15 @@ int derive_accel(rdx_buffer_s* tb)
         uint32_t masks = 0;
         for (uint32_t i = 0; i < nTop; ++i) if (tnodes[i].w0 & LEAF_BIT) masks += ((tnodes[i].w0 & 0x7fffffffu) + 15u) / 16u;
         ac->topFlat = (nTop <= 64 && masks <= 24) ? nTop : 0u;
+        // spare word of a top-level leaf: it holds instances whose BLAS is a single leaf of <= 8 triangles (pool engine)
+        for (uint32_t i = 0; i < nTop; ++i) {
+            dT[i].w3 = 0;
+            if (!(tnodes[i].w0 & LEAF_BIT)) continue;
+            for (uint32_t k = 0; k < (tnodes[i].w0 & 0x7fffffffu); ++k) {
+                const DInst& di = dI[tnodes[i].w1 + k];
+                if ((di.rootDesc1 & WIDE_LEAF) && (di.rootDesc1 & 0x7fffffffu) <= 8u) { dT[i].w3 = 1; ac->leafRoots = true; }
+            }
+        }
         ac->topFlatNeed = masks + 1u;
     }
     ac->blasNeed = maxBlasCoop;
@@ -389,6 +400,7 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.topNeed = tb->accel->topNeed; v.blasNeed = tb->accel->blasNeed;
     v.topFlat = g.topFlat ? tb->accel->topFlat : 0u;
     if (v.topFlat) v.topNeed = std::max(v.topNeed, tb->accel->topFlatNeed);
+    v.leafRoots = (v.topFlat && g.inlineLeafRoots && tb->accel->leafRoots) ? 1u : 0u;
     return v;
 }
 
@@ -898,6 +910,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
+    if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
 }

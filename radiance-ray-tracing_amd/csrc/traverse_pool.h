@@ -57,7 +57,10 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
 #define POOL_IDLE_MIN 32               // finished / free lanes a hand-over step waits for (16: +13 %, 24: +4 %, 40-48: +0-3 % frame time)
 #endif
 
-template <int REC, class Policy>
+// INL: the scene has instances whose BLAS is a single leaf of <= 8 triangles; they are handled inside the top-level step
+// (below).  A separate instantiation, chosen by the host per scene: the kernel sits at its register budget, and the extra
+// code costs scenes without such instances 10-15 % through spills even when it never runs.
+template <int REC, bool INL, class Policy>
 __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
                                               float tmin, float tmax, uint32_t* __restrict__ lds)
 {
@@ -226,11 +229,41 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                             if (r && slab_fast(W, mk3(bmin.x, bmin.y, bmin.z), mk3(bmax.x, bmax.y, bmax.z))) reach |= (1ull << w.x) | (1ull << w.y);
                         } else if (w.z == TYPE_INST && r) {
                             const uint32_t count = w.x & 0x7fffffffu;
-                            for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
-                                uint32_t m16 = 0;
-                                for (uint32_t k = 0; k < min(16u, count - b0); ++k)
-                                    if (coop_inst_pretest(A.insts[w.y + b0 + k], o, W.rcp, oMax, preOK)) m16 |= 1u << k;
-                                if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                            if (INL && w.w != 0u) {
+                                // this leaf holds instances whose BLAS is one small leaf (a quad: 2 triangles; flagged by
+                                // derive_accel in the node's spare word).  They are dealt with on the spot: matrix and
+                                // triangles are the same for all lanes of the step (scalar loads), each lane transforms its
+                                // own ray with the reference's expressions and runs the branch-free Moeller-Trumbore -- no
+                                // instance step, no parked ray, no queued tests for them.
+                                for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
+                                    uint32_t m16 = 0;
+                                    for (uint32_t k = 0; k < min(16u, count - b0); ++k) {
+                                        const uint32_t ci = w.y + b0 + k;              // the same instance for every lane here
+                                        const DInst& I = A.insts[ci];
+                                        const uint32_t rcnt = I.rootDesc1 & 0x7fffffffu;
+                                        if ((I.rootDesc1 & WIDE_LEAF) && rcnt <= 8u) {
+                                            if (!((REC != 1) && anyHit && L.best[lane] != ~0ull)) {
+                                                const f3 ro = mat4_mul3(I.inv, o.x, o.y, o.z, 1.0f);
+                                                const f3 rd = mat4_mul3(I.inv, d.x, d.y, d.z, 0.0f);
+                                                for (uint32_t j = 0; j < rcnt; ++j) {
+                                                    float t, b1, b2;
+                                                    if (coop_triangle(A, I.rootDesc0 + j, ro, rd, tmin, tmax, t, b1, b2)) {
+                                                        const uint32_t low = (ci << COOP_INST_SHIFT) | (I.rootDesc0 + j - I._p0);
+                                                        atomicMin(&L.best[lane], ((unsigned long long)__float_as_uint(t) << 32) | low);
+                                                    }
+                                                }
+                                            }
+                                        } else if (coop_inst_pretest(I, o, W.rcp, oMax, preOK)) m16 |= 1u << k;
+                                    }
+                                    if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                                }
+                            } else {
+                                for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
+                                    uint32_t m16 = 0;
+                                    for (uint32_t k = 0; k < min(16u, count - b0); ++k)
+                                        if (coop_inst_pretest(A.insts[w.y + b0 + k], o, W.rcp, oMax, preOK)) m16 |= 1u << k;
+                                    if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                                }
                             }
                         }
                     }
