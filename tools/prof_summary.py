@@ -22,7 +22,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]      # (template arguments dropped: k_fused_pool<true> -> k_fused_pool)
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
     return {k: {"launches": v[0], "avg_KiB_per_launch": v[1] / v[0]} for k, v in agg.items()}
