@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, help="-1 library default, 0 staged wavefront, 1 whole paths in one persistent launch")
     ap.add_argument("--kernel", type=int, default=-1, help="-1 library default; 2 cooperative, 3 cooperative with a shared node pool, 1 / 0 per-lane")
     ap.add_argument("--top-flat", type=int, default=-1, help="-1 library default; 0/1: evaluate small top-level trees all at once (pool engine)")
+    ap.add_argument("--groups", type=int, default=-1, help="-1 library default; 1..4 sample groups of a chunk on their own streams")
     ap.add_argument("--also", default="", help="comma list of extra workloads to time (reported under 'also')")
     args = ap.parse_args()
 
@@ -177,6 +178,8 @@ def main():
         rd.SetOption("pipeline", args.pipeline)
     if args.top_flat >= 0:
         rd.SetOption("top_flat", args.top_flat)
+    if args.groups >= 1:
+        rd.SetOption("groups", args.groups)
     if args.kernel >= 0:
         rd.SetOption("kernel", args.kernel)
         global ENGINE
@@ -225,6 +228,7 @@ def main():
             for k in ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulate", "ms_total", "ms_fused", "ms_path"):
                 acc[k] += getattr(st, k)
             acc["launches_extend"] += st.launches_extend
+            acc["groups"] = int(st.groups)
         sync()
         dt = time.perf_counter() - t0
         rd.SetProfiling(False)
@@ -284,7 +288,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": label, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth,
                    "sharding": "none" if world == 1 else "64x64 image tiles interleaved over %d ranks + RGBA8 gather" % world,
-                   "traversal": "exact (reference visit set and order)"},
+                   "traversal": "exact (reference visit set and order)",
+                   # sample groups traced concurrently on their own streams (library rule: 2 for chunks of <= 4.7 M paths);
+                   # with more than one, the per-launch durations behind `roofline` overlap in time: `achieved` is a lower bound
+                   "sample_groups": acc.get("groups", 1)},
         "rays_per_frame": {"primary": acc["primary"] // steps, "bounce": acc["bounce"] // steps, "shadow": acc["shadow"] // steps,
                            "note": "rank 0 share" if world > 1 else "whole frame"},
         "Mrays_per_s_primary_plus_bounce": round(rays_pb / dt / 1e6, 3),

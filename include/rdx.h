@@ -145,6 +145,8 @@ typedef struct rdx_trace_stats {
     float    ms_generate, ms_extend, ms_shade, ms_shadow, ms_accumulate, ms_fused;  /* ms_fused: shadow(d)+extend(d+1) launches */
     float    ms_path;                                  /* whole-path launches ("pipeline" 1) */
     uint32_t launches_extend, launches_shadow;
+    uint32_t groups;                                   /* sample groups the last chunk was traced in (option "groups") */
+    uint32_t reserved;
 } rdx_trace_stats;
 int         rdx_get_trace_stats(rdx_trace_stats* out);
 /* per-bounce visit counters of the last frame traced with "count_visits": out[8*d + 4*c + k], c = 0
@@ -166,8 +168,11 @@ int         rdx_set_profiling(int on);
  * wavefront: one launch per stage per bounce (default); 1 = whole paths -- camera ray to path end -- in one
  * persistent cooperative launch per sample chunk), "fuse" (1 / -1 = on (default), 0 = off:
  * trace the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch, which
- * halves the fixed ramp + tail cost per bounce), "overlap" and
- * "groups" (experimental: second-stream overlap / concurrent sample groups; off by default) */
+ * halves the fixed ramp + tail cost per bounce), "groups" (0 (default) = automatic, 1..4: the samples of a chunk are
+ * traced as that many independent groups on their own streams, each launching its share of the persistent grid, so
+ * that one group's launches fill the ramp and drain of the others'; automatic = 2 for chunks of <= 4.7 M paths with
+ * at least 2 samples (shards of a multi-GPU frame, low resolutions), else 1; results do not depend on it), "overlap"
+ * (experimental: shadow rays on a second stream when "fuse" is 0; off by default) */
 int         rdx_set_option(const char* name, int64_t value);
 
 /* Test seams: run single stages on caller-supplied batches (device or host pointers are NOT

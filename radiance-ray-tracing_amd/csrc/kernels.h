@@ -63,6 +63,10 @@ struct PathStreams {
     float4* sampleColor; // [samples_in_chunk][pixels] final per-sample radiance
 };
 
+// how many persistent traversal launches are to share the GPU from now on (sample groups on their own streams):
+// each launch takes 1/groups of the resident grid.  Host state, set by rdx_trace_rays per chunk.
+void set_grid_share(uint32_t groups);
+
 void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& ps, const uint32_t* ownedPixels,
                      uint32_t nPixels, uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples);
 // nPtr: device word holding the live count of this stage; nMax: upper bound used to size the grid

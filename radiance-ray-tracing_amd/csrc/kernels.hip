@@ -1107,13 +1107,20 @@ static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsByte
     ldsBytes = perWave * (threads / 64);
     return threads;
 }
+static uint32_t g_gridShare = 1;       // host side: how many concurrent persistent launches share the GPU (set per chunk)
+void set_grid_share(uint32_t groups) { g_gridShare = groups ? groups : 1; }
+
 // persistent grid: enough blocks to fill every CU at the LDS-limited residency, never more than the work
 static inline uint32_t coop_blocks(uint32_t nMax, uint32_t threads, size_t ldsBytes)
 {
     const uint32_t perCU = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(ldsBytes, 1), (64u * 4u * COOP_WPE) / threads));
     // small launches: enough waves that each is handed COOP_MIN_QUOTA rays (its other lanes help, traverse_coop.h)
     const uint64_t spread = COOP_STEAL ? (uint64_t)nMax * (64u / COOP_MIN_QUOTA) : nMax;
-    return (uint32_t)std::min<uint64_t>((spread + threads - 1) / threads, 256u * perCU);
+    // launches of different sample groups share the GPU: each takes its part of the resident grid
+    // (experiment knob RDX_COOP_GRID_DIV overrides the divisor)
+    static const int envDiv = std::getenv("RDX_COOP_GRID_DIV") ? std::max(1, std::atoi(std::getenv("RDX_COOP_GRID_DIV"))) : 0;
+    const uint32_t div = envDiv ? (uint32_t)envDiv : g_gridShare;
+    return (uint32_t)std::min<uint64_t>((spread + threads - 1) / threads, std::max(1u, 256u * perCU / div));
 }
 
 void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,

@@ -103,7 +103,7 @@ struct Context {
     size_t sampleCap = 0;
     float4* sampleColor = nullptr;
     uint32_t* dCounts = nullptr;            // = groups[0].dCounts (test seams)
-    int groupsOpt = 1;                      // sample groups in flight (experimental): 1..4
+    int groupsOpt = 0;                      // sample groups in flight: 1..4, 0 = two for chunks small enough to be ramp + drain bound
     int fuse = -1;                          // shadow(d) + extend(d+1) in one launch: 1 / -1 on, 0 off
     int pathMode = 0;                       // 0 = staged wavefront (launch per stage per bounce), 1 = whole paths in one launch
     unsigned long long* dVisit = nullptr;   // 8 words
@@ -905,7 +905,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!name) return fail("rdx_set_option: null name");
     if (!strcmp(name, "chunk_paths")) { if (value < 1) return fail("chunk_paths must be >= 1"); g.chunkPaths = value; return 0; }
     if (!strcmp(name, "count_visits")) { g.countVisits = value != 0; return 0; }
-    if (!strcmp(name, "groups")) { if (value < 1 || value > Context::MAX_GROUPS) return fail("groups must be 1..4"); g.groupsOpt = (int)value; return 0; }
+    if (!strcmp(name, "groups")) { if (value < 0 || value > Context::MAX_GROUPS) return fail("groups must be 0 (auto) or 1..4"); g.groupsOpt = (int)value; return 0; }
     if (!strcmp(name, "overlap")) { if (value < 0 || value > 1) return fail("overlap must be 0 or 1"); g.overlap = (int)value; return 0; }
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
@@ -992,11 +992,16 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         const uint32_t sc_n = std::min(samplesPerChunk, batch - s0);
         const uint32_t sampleBase = rt.totalSamples + s0;
         const uint64_t chunkPaths = (uint64_t)sc_n * P;
-        // Small chunks (multi-GPU shards, low resolutions) no longer fill the GPU with one launch and every
-        // traversal launch ends in a tail of a few long rays: split the chunk's samples into up to 4 groups
-        // with their own streams, so the launches of one group run inside the tails of the others.
-        const bool small = chunkPaths <= (4ull << 20);
-        int nGroups = (int)std::min<uint32_t>((uint32_t)(visit ? 1 : g.groupsOpt), sc_n);
+        // Small chunks (multi-GPU shards, low resolutions): a persistent traversal launch costs ~0.19 ms of ramp +
+        // drain whatever its size (profiles/r01k_timeline_eighth_before_groups.txt: 9 launches = 1.7 of the 3.7 ms of a 1/8 frame).
+        // The chunk's samples are split into groups with their own streams and counts, each launching 1/nGroups of
+        // the resident grid, so that one group's launches run inside the ramp and drain of the other's
+        // (kernels.hip: set_grid_share).  Two groups: -5 % at 1/8, -3 % at 1/2 of a 1080p x 4 spp frame; four: slower.
+        const bool small = chunkPaths <= (9ull << 19) && sc_n >= 2 && av.kernel >= 2;      // <= 4.7 M paths
+        const uint32_t wantGroups = visit ? 1u : g.groupsOpt ? (uint32_t)g.groupsOpt : small ? 2u : 1u;
+        int nGroups = (int)std::min<uint32_t>(wantGroups, sc_n);
+        set_grid_share((uint32_t)nGroups);
+        g.stats.groups = (uint32_t)nGroups;
         // Small chunks (multi-GPU shards, low resolutions): a traversal launch costs ~0.2 ms of ramp + tail
         // whatever its size (tools/trav_scale.py), so shadow(d) and extend(d+1) -- same ray count, disjoint
         // streams -- go into ONE cooperative launch: 9 traversal launches per depth-8 frame instead of 16.

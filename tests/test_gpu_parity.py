@@ -425,7 +425,8 @@ def test_fused_and_split_schedules_identical(mods):
     dev = scenes.DeviceScene(s)
     outs = []
     try:
-        for opts in ({"fuse": 1}, {"fuse": 0}, {"fuse": 0, "overlap": 1}, {"fuse": 0, "groups": 2}, {"pipeline": 1}):
+        for opts in ({"fuse": 1}, {"fuse": 0}, {"fuse": 0, "overlap": 1}, {"fuse": 0, "groups": 2}, {"groups": 2}, {"groups": 0},
+                     {"groups": 4}, {"pipeline": 1}):
             for k, v in {"fuse": -1, "overlap": 0, "groups": 1, "pipeline": 0, **opts}.items():
                 rd.SetOption(k, v)
             dev.set_rtprop(totalSamples=0); dev.clear_scratch()
@@ -433,7 +434,7 @@ def test_fused_and_split_schedules_identical(mods):
             st = rd.GetTraceStats()
             outs.append((dev.read_scratch().copy(), st.rays_bounce, st.rays_shadow))
     finally:
-        rd.SetOption("fuse", -1); rd.SetOption("overlap", 0); rd.SetOption("groups", 1); rd.SetOption("pipeline", 0)
+        rd.SetOption("fuse", -1); rd.SetOption("overlap", 0); rd.SetOption("groups", 0); rd.SetOption("pipeline", 0)
     for o in outs[1:]:
         assert np.array_equal(_bits(outs[0][0]), _bits(o[0])) and outs[0][1:] == o[1:]
 
