@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpu_eighth.sh -- per-dispatch timeline (duration + gap to the previous dispatch) of the last frame of a 1/8-frame
+# gpu_eighth.sh -- per-dispatch timeline (queue, start, duration) of the last frame of a 1/8-frame
 # run (one rank of eight) next to the full frame, from rocprofv3 --kernel-trace
 set -e
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/eighth; mkdir -p $OUT; cd /tmp
@@ -11,18 +11,18 @@ import csv, sys, glob
 f = glob.glob(sys.argv[1] + '/**/r1_kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if 'rdx::' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# last frame = from the last k_generate on
-last = max(i for i, r in enumerate(rows) if 'k_generate' in r['Kernel_Name'])
-fr = rows[last:]
-t0 = int(fr[0]['Start_Timestamp']); prev_end = t0
-print('==', sys.argv[2], 'frame total %.3f ms' % ((int(fr[-1]['End_Timestamp']) - t0) / 1e6))
+# last frame = the dispatches between the last two k_accumulate (with sample groups a frame has several k_generate)
+acc = [i for i, r in enumerate(rows) if 'k_accumulate' in r['Kernel_Name']]
+fr = rows[acc[-2] + 1:acc[-1] + 1]
+t0 = int(fr[0]['Start_Timestamp'])
+print('==', sys.argv[2], 'frame total %.3f ms' % ((max(int(r['End_Timestamp']) for r in fr) - t0) / 1e6))
 busy = 0
 for r in fr:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('rdx::', '')
-    print('  %-28s dur %8.1f us  gap %6.1f us  grid %s wg %s' % (name[:28], (e - s) / 1e3, (s - prev_end) / 1e3, r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?'))))
-    busy += e - s; prev_end = e
-print('  busy %.3f ms' % (busy / 1e6))
+    print('  q%-2s %-24s start %8.1f us  dur %8.1f us  grid %s wg %s' % (r['Queue_Id'], name[:24], (s - t0) / 1e3, (e - s) / 1e3, r['Grid_Size_X'], r['Workgroup_Size_X']))
+    busy += e - s
+print('  sum of durations %.3f ms' % (busy / 1e6))
 PY
 done > $OUT/timeline.txt 2>&1
 cat $OUT/timeline.txt
