@@ -432,6 +432,8 @@ def test_fused_and_split_schedules_identical(mods):
             dev.set_rtprop(totalSamples=0); dev.clear_scratch()
             dev.render()
             st = rd.GetTraceStats()
+            # 0 = automatic: two groups for a chunk this small; the whole-path pipeline has no groups
+            assert st.groups == (opts.get("groups", 1) or 2) or "pipeline" in opts
             outs.append((dev.read_scratch().copy(), st.rays_bounce, st.rays_shadow))
     finally:
         rd.SetOption("fuse", -1); rd.SetOption("overlap", 0); rd.SetOption("groups", 0); rd.SetOption("pipeline", 0)
