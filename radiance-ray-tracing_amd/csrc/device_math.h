@@ -1,10 +1,24 @@
 // device_math.h -- fp32 vector helpers for the HIP stages.
 //
-// Every expression is written out scalar-by-scalar in the evaluation order the reference's OpenCL C
-// implies, and the translation unit is compiled with -ffp-contract=off, so the +,-,*,/ and sqrt
-// results are the IEEE-754 values (hipcc's default fp32 divide/sqrt are correctly rounded).
-// OpenCL builtins are pinned to: min(x,y) = y<x?y:x, max(x,y) = x<y?y:x, clamp = min(max(x,lo),hi),
-// mix(a,b,t) = a+(b-a)*t, dot accumulated x->y->z(->w), normalize(v) = v / sqrt(dot(v,v)).
+// Floating-point contract: every value is what the REFERENCE's OpenCL C source computes when it
+// is compiled for this GPU by ROCm's own OpenCL C compiler with `-ffp-contract=off
+// -cl-fp32-correctly-rounded-divide-sqrt` and linked against ROCm's OpenCL builtin library (opencl.bc / ocml.bc /
+// ockl.bc of /opt/rocm/amdgcn/bitcode) -- the build oracle/Makefile makes as oracle/_ref/ref_shader_gfx950_p.co and
+// the GPU tests run next to these kernels.  Concretely:
+//   * user expressions: written out scalar-by-scalar in the evaluation order the OpenCL C source implies, this unit is
+//     compiled with -ffp-contract=off, hipcc's fp32 divide / sqrt are correctly rounded;
+//   * OpenCL builtins: restated below exactly as that library implements them (read from its bitcode):
+//       dot(a,b)     = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))              (fmuladd chain -> v_fma_f32 on gfx950)
+//       cross(a,b).x = fma(a.y,b.z, -(a.z*b.y)), .y, .z cyclic
+//       min / max / fmax = llvm.minnum / maxnum (v_min_f32 / v_max_f32: a NaN operand is dropped)
+//       clamp(x,lo,hi)   = v_med3_f32(x, lo, hi)
+//       mix(a,b,t)       = fma(b - a, t, a)
+//       normalize(v)     = v * rsqrt(dot(v,v)) with rsqrt = v_rsq_f32 (and the library's rescaling of tiny / huge
+//                          inputs), NOT v / sqrt(dot)
+//       sin cos acos pow sqrt: the same OCML functions hipcc links for sinf cosf acosf powf sqrtf.
+//   The CPU oracle (oracle/rt_oracle.c) restates the same contract with fmaf(); it cannot reproduce v_rsq_f32 and the
+//   OCML transcendentals bit for bit, so CPU-vs-GPU comparisons of anything behind a normalize carry a tolerance,
+//   while GPU-vs-reference-on-GPU comparisons are bit-exact.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,20 +38,53 @@ __device__ __forceinline__ f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y
 __device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ f3 one_minus(f3 a) { return mk3(1.0f - a.x, 1.0f - a.y, 1.0f - a.z); }
 
-__device__ __forceinline__ float cl_min(float x, float y) { return y < x ? y : x; }
-__device__ __forceinline__ float cl_max(float x, float y) { return x < y ? y : x; }
-__device__ __forceinline__ float cl_clamp(float x, float lo, float hi) { return cl_min(cl_max(x, lo), hi); }
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float cl_min(float x, float y) { return __builtin_fminf(x, y); }     // __ocml_min_f32
+__device__ __forceinline__ float cl_max(float x, float y) { return __builtin_fmaxf(x, y); }     // __ocml_max_f32 / fmax
+__device__ __forceinline__ float cl_clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }   // __ockl_median3_f32
+__device__ __forceinline__ float cl_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return cl_fma(a.z, b.z, cl_fma(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float dot4(f4 a, f4 b) { return cl_fma(a.w, b.w, cl_fma(a.z, b.z, cl_fma(a.y, b.y, a.x * b.x))); }
 __device__ __forceinline__ f3 cross3(f3 a, f3 b)
 {
-    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return mk3(cl_fma(a.y, b.z, b.y * (-a.z)), cl_fma(a.z, b.x, b.z * (-a.x)), cl_fma(a.x, b.y, b.x * (-a.y)));
 }
-__device__ __forceinline__ f3 normalize3(f3 v) { return v / sqrtf(dot3(v, v)); }
+__device__ __forceinline__ f3 mix3(f3 a, f3 b, float t)
+{
+    return mk3(cl_fma(b.x - a.x, t, a.x), cl_fma(b.y - a.y, t, a.y), cl_fma(b.z - a.z, t, a.z));
+}
+// __ocml_rsqrt_f32 with fp32 denormals enabled (the mode of both code objects): v_rsq_f32, denormal inputs rescaled
+__device__ __forceinline__ float cl_rsqrt(float x)
+{
+    const bool tiny = x < 0x1p-126f;
+    const float r = __builtin_amdgcn_rsqf(tiny ? x * 0x1p+24f : x);
+    return tiny ? r * 4096.0f : r;
+}
+__device__ __forceinline__ float cl_sel01(float v) { return __builtin_copysignf(__builtin_isinf(v) ? 1.0f : 0.0f, v); }
+// normalize(float3) / normalize(float4) of opencl.bc: zero vector unchanged; |v|^2 below FLT_MIN -> scaled by 2^86,
+// infinite -> scaled by 2^-66 (and, if still infinite, replaced by the +-1 / 0 pattern of its infinite components)
+__device__ __forceinline__ f3 normalize3(f3 v)
+{
+    if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return v;
+    float l2 = dot3(v, v);
+    if (l2 < 0x1p-126f) { v = v * 0x1p+86f; l2 = dot3(v, v); }
+    else if (l2 == __builtin_inff()) {
+        v = v * 0x1p-66f; l2 = dot3(v, v);
+        if (l2 == __builtin_inff()) { v = mk3(cl_sel01(v.x), cl_sel01(v.y), cl_sel01(v.z)); l2 = dot3(v, v); }
+    }
+    return v * cl_rsqrt(l2);
+}
 __device__ __forceinline__ f4 normalize4(f4 v)
 {
-    float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-    f4 r; r.x = v.x / l; r.y = v.y / l; r.z = v.z / l; r.w = v.w / l;
-    return r;
+    if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f) return v;
+    float l2 = dot4(v, v);
+    if (l2 < 0x1p-126f) { v.x *= 0x1p+86f; v.y *= 0x1p+86f; v.z *= 0x1p+86f; v.w *= 0x1p+86f; l2 = dot4(v, v); }
+    else if (l2 == __builtin_inff()) {
+        v.x *= 0x1p-66f; v.y *= 0x1p-66f; v.z *= 0x1p-66f; v.w *= 0x1p-66f; l2 = dot4(v, v);
+        if (l2 == __builtin_inff()) { v.x = cl_sel01(v.x); v.y = cl_sel01(v.y); v.z = cl_sel01(v.z); v.w = cl_sel01(v.w); l2 = dot4(v, v); }
+    }
+    const float r = cl_rsqrt(l2);
+    f4 o; o.x = v.x * r; o.y = v.y * r; o.z = v.z * r; o.w = v.w * r;
+    return o;
 }
 
 // row-major 4x4 times (x,y,z,w): the four-term sums of math.cl:25-31, kept in full so that zero

@@ -67,6 +67,8 @@ struct PathStreams {
 // each launch takes 1/groups of the resident grid.  Host state, set by rdx_trace_rays per chunk.
 void set_grid_share(uint32_t groups);
 
+// cos / sin of the three camera angles, evaluated on the device (out6 = cx sx cy sy cz sz, device memory)
+void launch_euler_trig(hipStream_t st, float wx, float wy, float wz, float* out6);
 void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& ps, const uint32_t* ownedPixels,
                      uint32_t nPixels, uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples);
 // nPtr: device word holding the live count of this stage; nMax: upper bound used to size the grid

@@ -373,6 +373,17 @@ __device__ __forceinline__ void camera_ray(const CameraArgs& C, uint32_t pixel, 
     dir = normalize3(focus - org);
 }
 
+// EulerX/Y/ZToMat4x4 (math.cl:185-252) take cos / sin of the camera angles per ray; they are per-frame constants, so
+// one thread evaluates them once -- on the device, with the OCML functions the reference's cos() / sin() link
+__global__ void k_euler_trig(float wx, float wy, float wz, float* __restrict__ out6)
+{
+    out6[0] = cosf(wx); out6[1] = sinf(wx); out6[2] = cosf(wy); out6[3] = sinf(wy); out6[4] = cosf(wz); out6[5] = sinf(wz);
+}
+void launch_euler_trig(hipStream_t st, float wx, float wy, float wz, float* out6)
+{
+    hipLaunchKernelGGL(k_euler_trig, dim3(1), dim3(1), 0, st, wx, wy, wz, out6);
+}
+
 __global__ void __launch_bounds__(RDX_BLOCK)
 k_generate(CameraArgs C, PathStreams ps, const uint32_t* __restrict__ owned, uint32_t nPixels, uint32_t sampleBegin,
            uint32_t sampleCount, uint32_t totalSamples)

@@ -460,15 +460,32 @@ int ensure_owned(uint32_t w, uint32_t h)
     return 0;
 }
 
-void camera_args(const PhysicalCamera& cam, CameraArgs& C)
+int camera_args(const PhysicalCamera& cam, CameraArgs& C)
 {
     C.cam = cam;
-    // EulerX/Y/ZToMat4x4 (math.cl:185-252): per-frame constants, evaluated once with libm
-    const float cx = cosf(cam.wx), sx = sinf(cam.wx), cy = cosf(cam.wy), sy = sinf(cam.wy), cz = cosf(cam.wz), sz = sinf(cam.wz);
+    // EulerX/Y/ZToMat4x4 (math.cl:185-252): per-frame constants.  cos / sin are evaluated ON THE DEVICE (k_euler_trig) so
+    // that they are the OCML values the reference's own cos() / sin() give on this GPU -- libm's differ in the last bit
+    // and every primary ray would with them; the six values are cached until the camera angles change.
+    static float cachedAngles[3] = {0, 0, 0}, cachedTrig[6] = {1, 0, 1, 0, 1, 0};
+    static bool cached = false;
+    if (!cached || std::memcmp(cachedAngles, &cam.wx, 12) != 0) {
+        float* d6 = nullptr;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&d6), 6 * sizeof(float)));
+        launch_euler_trig(g.stream, cam.wx, cam.wy, cam.wz, d6);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(cachedTrig, d6, sizeof cachedTrig, hipMemcpyDeviceToHost, g.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+        HIP_IGN(hipFree(d6));
+        HIP_OK(e);
+        std::memcpy(cachedAngles, &cam.wx, 12);
+        cached = true;
+    }
+    const float cx = cachedTrig[0], sx = cachedTrig[1], cy = cachedTrig[2], sy = cachedTrig[3], cz = cachedTrig[4], sz = cachedTrig[5];
     const float rx[16] = {1, 0, 0, 0, 0, cx, -sx, 0, 0, sx, cx, 0, 0, 0, 0, 1};
     const float ry[16] = {cy, 0, sy, 0, 0, 1, 0, 0, -sy, 0, cy, 0, 0, 0, 0, 1};
     const float rz[16] = {cz, -sz, 0, 0, sz, cz, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::memcpy(C.rotX, rx, 64); std::memcpy(C.rotY, ry, 64); std::memcpy(C.rotZ, rz, 64);
+    return 0;
 }
 
 int scene_args(SceneArgs& sc)
@@ -963,7 +980,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
     if (bCam->mirrorValid && bCam->mirror.size() >= sizeof cam) std::memcpy(&cam, bCam->mirror.data(), sizeof cam);
     else HIP_OK(hipMemcpy(&cam, bCam->dptr, sizeof cam, hipMemcpyDeviceToHost));
     CameraArgs C;
-    camera_args(cam, C);
+    if (camera_args(cam, C)) return -1;
     if ((uint32_t)cam.widthPixel == 0) return fail("TraceRays: camera widthPixel is 0");
 
     if (ensure_owned(width, height)) return -1;
@@ -1213,7 +1230,7 @@ extern "C" int rdx_generate_batch(const uint32_t* pixels, const uint32_t* rnd, u
     PhysicalCamera cam;
     HIP_OK(hipMemcpy(&cam, static_cast<rdx_buffer_s*>(g.slots[3])->dptr, sizeof cam, hipMemcpyDeviceToHost));
     CameraArgs C;
-    camera_args(cam, C);
+    if (camera_args(cam, C)) return -1;
     DevArray<uint32_t> dP, dR; DevArray<float> dO, dD;
     HIP_OK(dP.upload(pixels, n)); HIP_OK(dR.upload(rnd, 3 * (size_t)n)); HIP_OK(dO.alloc(3 * (size_t)n)); HIP_OK(dD.alloc(3 * (size_t)n));
     launch_generate_batch(g.stream, C, dP.p, dR.p, n, dO.p, dD.p);

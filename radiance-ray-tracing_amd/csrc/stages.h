@@ -45,7 +45,7 @@ struct Payload {                    // struct Payload, shader.cl:4-13 (+ the def
 // ---------------------------------------------------------------------------------------------
 __device__ inline void normal_space(f3 n, float* m)   // math.cl:269-298 GetNormalSpace
 {
-    float dd = 1.0f * n.x + 0.0f * n.y + 0.0f * n.z;
+    float dd = dot3(mk3(1.0f, 0.0f, 0.0f), n);
     f3 tangent = mk3(0.0f, 1.0f, 0.0f);
     if (1.0f - fabsf(dd) > 1e-6f) tangent = normalize3(cross3(mk3(1.0f, 0.0f, 0.0f), n));
     f3 bitangent = cross3(n, tangent);
@@ -66,11 +66,8 @@ __device__ inline float d_ggx(float dotNH, float roughness)   // pbr.cl:6-13
 __device__ inline f3 f_schlick(float cosTheta, float metallic, f3 albedo)   // pbr.cl:31-37
 {
     const f3 lo = mk3(0.04f, 0.04f, 0.04f);
-    f3 F0 = lo + (albedo - lo) * metallic;
-    // pow(1 - cosTheta, 5): cosTheta is clamped to [0,1], so the base is in [0,1] and the product chain
-    // is within ~2 ulp of a correctly rounded pow (the oracle's powf and OCML's differ by as much)
-    const float x = 1.0f - cosTheta, x2 = x * x;
-    const float p = x2 * x2 * x;
+    f3 F0 = mix3(lo, albedo, metallic);
+    const float p = powf(1.0f - cosTheta, 5.0f);        // the same OCML pow the reference's pow(x, 5.0f) links
     return F0 + one_minus(F0) * p;
 }
 
@@ -99,7 +96,7 @@ __device__ inline float smith_lambda(f3 w, float a)   // pbr.cl:41-74 Lambda and
 struct NFrame { float tbn[9]; float inv[9]; };      // row-major 3x3
 __device__ inline void make_frame(f3 n, NFrame& F)
 {
-    float dd = 1.0f * n.x + 0.0f * n.y + 0.0f * n.z;
+    float dd = dot3(mk3(1.0f, 0.0f, 0.0f), n);
     f3 t = mk3(0.0f, 1.0f, 0.0f);
     if (1.0f - fabsf(dd) > 1e-6f) t = normalize3(cross3(mk3(1.0f, 0.0f, 0.0f), n));
     const f3 b = cross3(n, t);
@@ -119,6 +116,12 @@ __device__ inline void make_frame(f3 n, NFrame& F)
 __device__ __forceinline__ f3 mat3_mul(const float* m, float x, float y, float z)
 {
     return mk3(m[0] * x + m[1] * y + m[2] * z, m[3] * x + m[4] * y + m[5] * z, m[6] * x + m[7] * y + m[8] * z);
+}
+// the same with the `+ s3 * w` term of MultiplyMat4Vec4 for s3 = 0, w = 0 (a -0 sum becomes +0): used where the
+// result leaves the shader as a direction
+__device__ __forceinline__ f3 mat3_mul_w0(const float* m, float x, float y, float z)
+{
+    return mk3(m[0] * x + m[1] * y + m[2] * z + 0.0f, m[3] * x + m[4] * y + m[5] * z + 0.0f, m[6] * x + m[7] * y + m[8] * z + 0.0f);
 }
 
 __device__ inline float g_pbrt(const NFrame& F, f3 wo, f3 wi, float roughness)   // pbr.cl:77-96
@@ -162,7 +165,7 @@ __device__ inline f3 microfacet_brdf(const NFrame& FN, f3 L, f3 V, f3 N, f3 albe
 __device__ inline f3 frame_dir(const NFrame& F, float theta, float phi)
 {
     float st = sinf(theta), ct = cosf(theta), sp = sinf(phi), cp = cosf(phi);
-    return mat3_mul(F.tbn, st * cp, st * sp, ct);
+    return mat3_mul_w0(F.tbn, st * cp, st * sp, ct);
 }
 
 // pbr.cl:289-385 sampleMicrofacetBRDF_transm.  The diffuse and the specular lobe share the frame of N,
