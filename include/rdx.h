@@ -62,6 +62,11 @@ size_t      rdx_buffer_size(rdx_buffer b);
  *      The blobs are byte-identical to the reference's (layout: radiance/shader/data.cl:237-278). */
 rdx_blas    rdx_blas_build(const float* vertices_xyz, uint32_t nvertices,
                            const uint32_t* indices, uint32_t ntriangles);
+/* `count` meshes at once, built on a pool of host threads inside the library (the caller stays single-threaded);
+ * out[i] is what rdx_blas_build(verts[i], ...) would return.  The reference builds its meshes one after the other
+ * (tools/sceneBuilder.cpp:229-258); at 10 M triangles that serial loop is the whole scene-load time. */
+int         rdx_blas_build_many(uint32_t count, const float* const* verts_xyz, const uint32_t* nvertices,
+                                const uint32_t* const* indices, const uint32_t* ntriangles, rdx_blas* out);
 const void* rdx_blas_data(rdx_blas b, uint32_t* size_out);
 int         rdx_blas_max_depth(rdx_blas b);
 rdx_buffer  rdx_tlas_build(const rdx_instance* instances, uint32_t ninstances);

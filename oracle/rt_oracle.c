@@ -36,26 +36,53 @@ static inline f3 f3_scale(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s);
 static inline f3 f3_divs(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
 static inline f3 f3_neg(f3 a) { return F3(-a.x, -a.y, -a.z); }
 
-static inline float cl_min(float x, float y) { return y < x ? y : x; }
-static inline float cl_max(float x, float y) { return x < y ? y : x; }
-static inline float cl_clamp(float x, float lo, float hi) { return cl_min(cl_max(x, lo), hi); }
+/* OpenCL builtins as ROCm's OpenCL builtin library (opencl.bc / ocml.bc, ROCm 7.2) implements them for gfx950 -- the
+ * floating-point contract of the project (rt_oracle.h).  Exact on the CPU: dot / cross / mix (explicit fma chains),
+ * min / max (minnum / maxnum: a NaN operand is dropped), clamp (v_med3_f32).  NOT reproducible bit for bit on the CPU:
+ * normalize (v * v_rsq_f32(dot), a <= 1 ulp hardware approximation; here the correctly rounded 1/sqrt) and the OCML
+ * transcendentals (here glibc's) -- everything behind those carries a tolerance against the GPU. */
+static inline float cl_min(float x, float y) { return (x != x) ? y : ((y != y) ? x : (y < x ? y : x)); }
+static inline float cl_max(float x, float y) { return (x != x) ? y : ((y != y) ? x : (x < y ? y : x)); }
+static inline float cl_clamp(float x, float lo, float hi) { return (x != x) ? cl_min(lo, hi) : cl_min(cl_max(x, lo), hi); }
 static inline f3 cl_min3(f3 a, f3 b) { return F3(cl_min(a.x, b.x), cl_min(a.y, b.y), cl_min(a.z, b.z)); }
 static inline f3 cl_max3(f3 a, f3 b) { return F3(cl_max(a.x, b.x), cl_max(a.y, b.y), cl_max(a.z, b.z)); }
 static inline f3 cl_clamp3(f3 a, float lo, float hi) { return F3(cl_clamp(a.x, lo, hi), cl_clamp(a.y, lo, hi), cl_clamp(a.z, lo, hi)); }
-static inline float cl_dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-static inline float cl_dot4(f4 a, f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+static inline float cl_dot3(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+static inline float cl_dot4(f4 a, f4 b) { return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x))); }
 static inline f3 cl_cross(f3 a, f3 b)
 {
-    return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    return F3(__builtin_fmaf(a.y, b.z, b.y * (-a.z)), __builtin_fmaf(a.z, b.x, b.z * (-a.x)), __builtin_fmaf(a.x, b.y, b.x * (-a.y)));
 }
-static inline f3 cl_normalize3(f3 v) { float l = sqrtf(cl_dot3(v, v)); return f3_divs(v, l); }
+static inline float cl_rsqrt(float x) { return (float)(1.0 / sqrt((double)x)); }
+static inline float cl_sel01(float v) { return copysignf(isinf(v) ? 1.0f : 0.0f, v); }
+static inline f3 cl_normalize3(f3 v)
+{
+    if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f) return v;
+    float l2 = cl_dot3(v, v);
+    if (l2 < 0x1p-126f) { v = f3_scale(v, 0x1p+86f); l2 = cl_dot3(v, v); }
+    else if (l2 == INFINITY) {
+        v = f3_scale(v, 0x1p-66f); l2 = cl_dot3(v, v);
+        if (l2 == INFINITY) { v = F3(cl_sel01(v.x), cl_sel01(v.y), cl_sel01(v.z)); l2 = cl_dot3(v, v); }
+    }
+    return f3_scale(v, cl_rsqrt(l2));
+}
 static inline f4 cl_normalize4(f4 v)
 {
-    float l = sqrtf(cl_dot4(v, v));
-    f4 r = {v.x / l, v.y / l, v.z / l, v.w / l};
-    return r;
+    if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f) return v;
+    float l2 = cl_dot4(v, v);
+    if (l2 < 0x1p-126f) { v.x *= 0x1p+86f; v.y *= 0x1p+86f; v.z *= 0x1p+86f; v.w *= 0x1p+86f; l2 = cl_dot4(v, v); }
+    else if (l2 == INFINITY) {
+        v.x *= 0x1p-66f; v.y *= 0x1p-66f; v.z *= 0x1p-66f; v.w *= 0x1p-66f; l2 = cl_dot4(v, v);
+        if (l2 == INFINITY) { v.x = cl_sel01(v.x); v.y = cl_sel01(v.y); v.z = cl_sel01(v.z); v.w = cl_sel01(v.w); l2 = cl_dot4(v, v); }
+    }
+    const float r = cl_rsqrt(l2);
+    f4 o = {v.x * r, v.y * r, v.z * r, v.w * r};
+    return o;
 }
-static inline f3 cl_mix3(f3 a, f3 b, float t) { return f3_add(a, f3_scale(f3_sub(b, a), t)); }
+static inline f3 cl_mix3(f3 a, f3 b, float t)
+{
+    return F3(__builtin_fmaf(b.x - a.x, t, a.x), __builtin_fmaf(b.y - a.y, t, a.y), __builtin_fmaf(b.z - a.z, t, a.z));
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* math.cl                                                                                     */

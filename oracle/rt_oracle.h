@@ -14,25 +14,37 @@
  * (radiance-ray-tracing_amd/) never links, imports or calls it.
  *
  * PARITY PIN STATUS
- *   The reference has no tests, golden vectors or fixtures
- *   and cannot be built here as a whole: its host side needs the assimp
- *   headers (empty submodule) and its device side needs an OpenCL runtime's
- *   builtin library (no CPU OpenCL driver in the image).  What IS pinned by
- *   the real reference: the builtin-free device functions (random_pcg3d,
- *   InverseMat4x4, MultiplyMat4Vec4, MultiplyMat4Mat4, D_GGX), executed from
- *   the reference's own samples/shader.cl compiled for x86 by oracle/Makefile
- *   into oracle/_ref/ (see oracle/ref_harness.c, tests/golden/ref_*.npz), and
- *   the SBT row mapping produced by the reference's tools/genSBT.py.
- *   Everything else in this file is "parity unpinned": a restatement by
- *   reading, with the OpenCL builtins the driver would supply pinned to the
- *   definitions stated below.
+ *   The reference has no tests, golden vectors or fixtures.
+ *   Its HOST side (bvh.cpp / radiance.cpp) needs the assimp headers (empty
+ *   submodule): unbuildable here, so the SAH builder and the blob packers in this
+ *   file are "parity unpinned" (a restatement by reading).
+ *   Its DEVICE side is pinned to the real thing: oracle/Makefile compiles the
+ *   reference's own samples/shader.cl + radiance/shader/ *.cl, where they lie, with
+ *   ROCm clang's OpenCL C front end for gfx950 and links ROCm's own OpenCL builtin
+ *   library -- nothing stood in for -- into oracle/_ref/ref_shader_gfx950_p.co,
+ *   which tests/refgpu_bind.py runs on the MI355X.  Outputs of that code object
+ *   (slab test, triangle test, HitData of ray batches, `material` payloads,
+ *   primary rays, BRDF values, whole imageScratch / RGBA8 frames) are committed as
+ *   tests/golden/refgpu_*.npz (tests/golden/make_golden_gpu.py) and this oracle is
+ *   checked against them in the CPU suite; the HIP product is checked against the
+ *   same fixtures AND against the live code object in the GPU suite.
+ *   Also pinned by real reference code, on the CPU: random_pcg3d, InverseMat4x4,
+ *   MultiplyMat4Vec4 / Mat4, D_GGX (x86 build of shader.cl, oracle/ref_harness.c,
+ *   tests/golden/ref_kat.npz) and the SBT row mapping of tools/genSBT.py.
  *
- * Floating-point pin (OpenCL leaves these to the driver):
- *   no fp contraction (-ffp-contract=off), IEEE fp32 + - * / sqrt,
- *   min(x,y) = y<x ? y : x, max(x,y) = x<y ? y : x,
- *   clamp(x,lo,hi) = min(max(x,lo),hi), mix(a,b,t) = a + (b-a)*t,
- *   dot accumulated x->y->z(->w), cross per the OpenCL spec,
- *   normalize(v) = v / sqrt(dot(v,v)); sin/cos/acos/pow = libm float versions.
+ * Floating-point contract = what that reference build computes:
+ *   user code with -ffp-contract=off and -cl-fp32-correctly-rounded-divide-sqrt
+ *   (IEEE fp32 + - * / sqrt, nothing fused), OpenCL builtins as ROCm's library
+ *   implements them (read from its bitcode):
+ *     dot = fma chain (x*x', then fma y, fma z[, fma w]); cross.x = fma(a.y,b.z,-(a.z*b.y)), cyclic;
+ *     min/max/fmax = minnum/maxnum (NaN operand dropped); clamp = v_med3_f32; mix = fma(b-a,t,a);
+ *     normalize(v) = v * rsqrt(dot(v,v)) with v_rsq_f32; sin/cos/acos/pow = OCML.
+ *   This file reproduces dot/cross/min/max/clamp/mix exactly (fmaf); normalize uses
+ *   the correctly rounded 1/sqrt and sin/cos/acos/pow are glibc's, so: slab test,
+ *   triangle test and traversal of GIVEN rays are bit-exact against the reference
+ *   build; anything behind a normalize or a transcendental (primary rays, shading,
+ *   frames) agrees to a stated tolerance only.  The HIP product has no such limit:
+ *   it is bit-identical to the reference build throughout.
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H

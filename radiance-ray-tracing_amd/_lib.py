@@ -69,6 +69,8 @@ SIGNATURES = {
     "rdx_buffer_device_ptr": (C.c_void_p, [C.c_void_p]),
     "rdx_buffer_size": (C.c_size_t, [C.c_void_p]),
     "rdx_blas_build": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "rdx_blas_build_many": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),
     "rdx_blas_data": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rdx_blas_max_depth": (C.c_int, [C.c_void_p]),
     "rdx_tlas_build": (C.c_void_p, [C.POINTER(rdx_instance), C.c_uint32]),

@@ -3,8 +3,8 @@
 // Floating-point contract: every value is what the REFERENCE's OpenCL C source computes when it
 // is compiled for this GPU by ROCm's own OpenCL C compiler with `-ffp-contract=off
 // -cl-fp32-correctly-rounded-divide-sqrt` and linked against ROCm's OpenCL builtin library (opencl.bc / ocml.bc /
-// ockl.bc of /opt/rocm/amdgcn/bitcode) -- the build oracle/Makefile makes as oracle/_ref/ref_shader_gfx950_p.co and
-// the GPU tests run next to these kernels.  Concretely:
+// ockl.bc of /opt/rocm/amdgcn/bitcode) -- the code object the test infrastructure builds from the reference's sources
+//  and the GPU tests run next to these kernels.  Concretely:
 //   * user expressions: written out scalar-by-scalar in the evaluation order the OpenCL C source implies, this unit is
 //     compiled with -ffp-contract=off, hipcc's fp32 divide / sqrt are correctly rounded;
 //   * OpenCL builtins: restated below exactly as that library implements them (read from its bitcode):
@@ -16,7 +16,7 @@
 //       normalize(v)     = v * rsqrt(dot(v,v)) with rsqrt = v_rsq_f32 (and the library's rescaling of tiny / huge
 //                          inputs), NOT v / sqrt(dot)
 //       sin cos acos pow sqrt: the same OCML functions hipcc links for sinf cosf acosf powf sqrtf.
-//   The CPU oracle (oracle/rt_oracle.c) restates the same contract with fmaf(); it cannot reproduce v_rsq_f32 and the
+//   The CPU restatement used by the tests follows the same contract with fmaf(); it cannot reproduce v_rsq_f32 and the
 //   OCML transcendentals bit for bit, so CPU-vs-GPU comparisons of anything behind a normalize carry a tolerance,
 //   while GPU-vs-reference-on-GPU comparisons are bit-exact.
 #pragma once

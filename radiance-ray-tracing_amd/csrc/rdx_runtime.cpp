@@ -15,6 +15,8 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -666,6 +668,43 @@ extern "C" rdx_blas rdx_blas_build(const float* v, uint32_t nv, const uint32_t* 
     h->blas.reset(b);
     g.blases.push_back(std::move(h));
     return g.blases.back().get();
+}
+
+// Several meshes at once: the builds are independent (one BVH per mesh), so they run on a pool of host threads inside the
+// library -- the caller stays single-threaded (radiance.h has no such call; the reference builds its meshes one after the
+// other, tools/sceneBuilder.cpp:229-258).  Results are identical to `count` rdx_blas_build calls in order.
+extern "C" int rdx_blas_build_many(uint32_t count, const float* const* verts, const uint32_t* nverts,
+                                   const uint32_t* const* indices, const uint32_t* ntris, rdx_blas* out)
+{
+    if (count == 0) return 0;
+    if (!verts || !nverts || !indices || !ntris || !out) return fail("rdx_blas_build_many: null argument");
+    std::vector<Blas*> built(count, nullptr);
+    std::vector<std::string> errs(count);
+    std::atomic<uint32_t> next{0};
+    const uint32_t nthreads = std::max(1u, std::min(count, std::min(16u, std::thread::hardware_concurrency())));
+    auto work = [&]() {
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= count) return;
+            built[i] = build_blas(verts[i], nverts[i], indices[i], ntris[i], errs[i]);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    for (uint32_t i = 0; i < count; ++i)
+        if (!built[i]) {
+            for (Blas* b : built) delete b;
+            return fail("mesh %u: %s", i, errs[i].c_str());
+        }
+    for (uint32_t i = 0; i < count; ++i) {
+        auto h = std::make_unique<rdx_blas_s>();
+        h->blas.reset(built[i]);
+        g.blases.push_back(std::move(h));
+        out[i] = g.blases.back().get();
+    }
+    return 0;
 }
 
 extern "C" const void* rdx_blas_data(rdx_blas b, uint32_t* size_out)

@@ -170,6 +170,25 @@ def BuildAccelStruct(platform, what):
     return Buffer(h, L.rdx_buffer_size(h))
 
 
+def BuildAccelStructs(platform, meshes):
+    """[Mesh] -> [BottomAccelStruct], built concurrently inside the library (rdx_blas_build_many); same results as
+    BuildAccelStruct(platform, mesh) for each mesh in turn."""
+    L = _lib.lib()
+    meshes = list(meshes)
+    n = len(meshes)
+    if n == 0:
+        return []
+    vs = [np.ascontiguousarray(m.vertexData, np.float32).reshape(-1, 3) for m in meshes]
+    ts = [np.ascontiguousarray(m.indexData, np.uint32).reshape(-1, 3) for m in meshes]
+    vp = (C.c_void_p * n)(*[v.ctypes.data for v in vs])
+    tp = (C.c_void_p * n)(*[t.ctypes.data for t in ts])
+    nv = (C.c_uint32 * n)(*[v.shape[0] for v in vs])
+    nt = (C.c_uint32 * n)(*[t.shape[0] for t in ts])
+    out = (C.c_void_p * n)()
+    _check(L.rdx_blas_build_many(n, vp, nv, tp, nt, out))
+    return [BottomAccelStruct(_handle(out[i], "BuildAccelStructs")) for i in range(n)]
+
+
 def _instance_array(instances):
     arr = (_lib.rdx_instance * max(len(instances), 1))()
     for k, inst in enumerate(instances):

@@ -298,7 +298,7 @@ class DeviceScene:
             return buf
         self.meshInfoData = up(b["meshInfo"]); self.vertexData = up(b["vertex"]); self.indexData = up(b["index"])
         self.uvData = up(b["uv"]); self.normalData = up(b["normal"]); self.materialData = up(b["material"])
-        self.blas = [rd.BuildAccelStruct(plt, rd.Mesh(m[0], m[1])) for m in scene.meshes]
+        self.blas = rd.BuildAccelStructs(plt, [rd.Mesh(m[0], m[1]) for m in scene.meshes])
         insts = [rd.Instance(tf, 0, mat, self.blas[mi]) for (mi, tf, mat) in scene.instances]
         self.topAccelStruct = rd.BuildAccelStruct(plt, insts)
         self.descSet = rd.CreateDescriptorSet([
@@ -435,11 +435,26 @@ def c2_atrium(width=1920, height=1080, spp=4, depth=8, detail=1.0):
     return s
 
 
-def c4_atrium_10m(width=1920, height=1080, spp=4, depth=8):
-    """BASELINE config 4 ("San-Miguel-scale"): the atrium generator at 6.3x tessellation = 10.4 M unique
-    triangles, 25 instances; the acceleration blob (446 MB) exceeds L2 and the 256 MB Infinity Cache."""
-    s = c2_atrium(width, height, spp, depth, detail=6.3)
+def c4_atrium_10m(width=1920, height=1080, spp=4, depth=8, detail=6.3, foliage=64):
+    """BASELINE config 4 ("San-Miguel-scale", SURVEY.md 8d): the atrium generator at 6.3x tessellation = 10.4 M unique
+    triangles in 25 instances, plus `foliage` instances of ONE shared 5120-triangle BLAS (rotated / non-uniformly scaled
+    bushes along the nave and the aisles: the BLAS-deduplication path of the TLAS packer, radiance/src/bvh.cpp:575-588);
+    the acceleration blob (446 MB) exceeds L2 and the 256 MB Infinity Cache."""
+    s = c2_atrium(width, height, spp, depth, detail=detail)
     s.name = "c4_atrium_10m"
+    if foliage:
+        bush = s.add_mesh(icosphere(4, 1.0))
+        s.materials = list(s.materials) + [material((0.18, 0.42, 0.12), 0.0, 0.75)]
+        mat = len(s.materials) - 1
+        k = np.arange(foliage)
+        h = _hash01(k, k * 7 + 3, 977)
+        h2 = _hash01(k * 5 + 1, k, 978)
+        for i in range(foliage):
+            lane = (-9.5, -3.0, 3.0, 9.5)[i % 4]
+            z = -18.0 + 36.0 * (i // 4) / max(1, (foliage - 1) // 4)
+            sx, sy, sz = 0.45 + 0.5 * h[i], 0.5 + 0.9 * h2[i], 0.45 + 0.5 * h[(i * 3) % foliage]
+            tf = translate(lane + 0.8 * (h2[i] - 0.5), 0.55 * sy, z + 0.6 * (h[i] - 0.5)) @ rotate_y(360.0 * h[i]) @ scale(sx, sy, sz)
+            s.add_instance(bush, tf, mat)
     return s
 
 

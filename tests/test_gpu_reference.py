@@ -1,0 +1,249 @@
+"""GPU suite, part 2 (-m gpu): the HIP product against the REAL reference device code.
+
+Two comparands, both the reference's own samples/shader.cl + radiance/shader/*.cl compiled for gfx950 by ROCm clang
+against ROCm's OpenCL builtin library (oracle/Makefile -> oracle/_ref/ref_shader_gfx950_p.co, flags `-ffp-contract=off
+-cl-fp32-correctly-rounded-divide-sqrt` = the floating-point contract of DESIGN.md section 2):
+
+  * committed outputs of that code object (tests/golden/refgpu_*.npz, made by tests/golden/make_golden_gpu.py) --
+    always available;
+  * the code object itself, launched here next to the product (tests/refgpu_bind.py) -- it is built in the build
+    container, where /root/reference exists, and travels to the GPU box like the product's own librdx.so; tests that need
+    it skip when it is absent.
+
+Bar: BIT-EXACT everywhere -- HitData, primary rays, `material` payloads, whole imageScratch and RGBA8 frames, at the small
+golden sizes and at BASELINE's full sizes (configs 1-4)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+import oracle_bind as ob
+import refgpu_bind as rg
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIELDS = ("distance", "primitiveIndex", "instanceIndex", "instanceCustomIndex", "instanceSBTOffset", "barycentric",
+          "hitPoint", "transform")
+
+
+@pytest.fixture(scope="module")
+def mods(gpu):
+    import rrt_amd  # noqa: F401
+    from radiance_ray_tracing_amd import rd, scenes
+    return rd, scenes
+
+
+@pytest.fixture(scope="module")
+def ref(gpu):
+    if not rg.available("p"):
+        pytest.skip("oracle/_ref/ref_shader_gfx950_p.co is not built (needs /root/reference: `make -C oracle`)")
+    return rg.RefGpu("p")
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint8).reshape(a.shape[0], -1) if a.ndim else a.view(np.uint8)
+
+
+def _same_hits(ref_h, got, closest=True, tag=""):
+    assert np.array_equal(ref_h["hit"], got["hit"]), tag
+    if closest:
+        h = ref_h["hit"] == 1
+        for f in FIELDS:
+            assert np.array_equal(_bits(ref_h[f][h]), _bits(got[f][h])), (tag, f)
+
+
+def _ambient(scene, hits):
+    albedo = np.array(scene.materials)["albedo"][hits["instanceCustomIndex"], :3]
+    return (albedo * np.float32(0.1)).astype(np.float32)
+
+
+def _check_material(scene, hits, ref_pay, got):
+    """the product's seam reports the light-visible colour (its shadow query is a separate stage); the reference's colour
+    includes the shadow test -> it is bit-equal to the product's, or exactly the ambient term when the light is occluded"""
+    k = hits["hit"] == 1
+    assert np.array_equal(ref_pay["hit"][k], got["hit"][k])
+    for f in ("nextFactor", "nextRayOrigin", "nextRayDirection"):
+        assert np.array_equal(_bits(ref_pay[f][k]), _bits(got[f][k])), f
+    lit = (_bits(ref_pay["color"][k]) == _bits(got["color"][k])).all(1)
+    occluded = (_bits(ref_pay["color"][k]) == _bits(_ambient(scene, hits[k]))).all(1)
+    assert np.all(lit | occluded)
+    return int(lit.sum()), int(occluded.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# committed reference outputs
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["c0", "c1", "c2"])
+def test_product_matches_reference_goldens(mods, name):
+    rd, scenes = mods
+    G = np.load(os.path.join(GOLD, "refgpu_%s.npz" % name))
+    s = gc.small_scene(scenes, name)
+    dev = scenes.DeviceScene(s)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    assert np.array_equal(gc.sha(blob), G["blob_sha256"])
+    # traversal: all four kernels, closest hit and any hit
+    ref_h = np.ascontiguousarray(G["hits"]).view(ob.HIT_DTYPE).reshape(-1)
+    o, d = G["ray_o"], G["ray_d"]
+    _same_hits(ref_h, rd.TraceBatch(dev.topAccelStruct, o, d, reference_order=True), tag="reference-order kernel")
+    for kernel in (3, 2, 1):
+        rd.SetOption("kernel", kernel)
+        try:
+            _same_hits(ref_h, rd.TraceBatch(dev.topAccelStruct, o, d), tag="kernel %d" % kernel)
+            sh = rd.TraceBatch(dev.topAccelStruct, o, d, sbtRecordOffset=2)
+        finally:
+            rd.SetOption("kernel", 3)
+        assert np.array_equal(sh["hit"].astype(np.uint8), G["shadow_hit"]), kernel
+    assert (ref_h["hit"] == 1).sum() > 500
+    # primary rays: generateRay of every pixel (pinhole; thin lens for c1)
+    npix = s.width * s.height
+    px = np.arange(npix, dtype=np.uint32)
+    go, gd = rd.GenerateBatch(px, G["gen_rnd"])
+    assert np.array_equal(_bits(go), _bits(G["gen_o"])) and np.array_equal(_bits(gd), _bits(G["gen_d"]))
+    # `material` payloads on captured hits
+    hits = np.ascontiguousarray(G["mat_hits"]).view(ob.HIT_DTYPE).reshape(-1)
+    ref_pay = np.ascontiguousarray(G["mat_payload"]).view(ob.PAYLOAD_DTYPE).reshape(-1)
+    n = hits.shape[0]
+    frames, depths = gc.material_inputs(n)
+    got = rd.MaterialBatch(hits, G["mat_dir"], np.arange(n, dtype=np.uint32), frames, depths)
+    lit, occ = _check_material(s, hits, ref_pay, got)
+    assert lit > 100
+    # two progressive frames: imageScratch and RGBA8 bit for bit
+    for f in range(2):
+        img = dev.render()
+        assert np.array_equal(_bits(dev.read_scratch().reshape(-1)), _bits(G["scratch%d" % f])), f
+        assert np.array_equal(img.reshape(-1), G["image%d" % f]), f
+    if name == "c1":
+        dev2 = scenes.DeviceScene(gc.small_scene(scenes, name, fstop=2.8))
+        lo, ld = rd.GenerateBatch(px, G["gen_rnd"])
+        assert np.array_equal(_bits(lo), _bits(G["lens_o"])) and np.array_equal(_bits(ld), _bits(G["lens_d"]))
+        del dev2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the live reference code object
+# ---------------------------------------------------------------------------------------------------------------------
+def _frames_identical(rd, dev, rs, frames=1, rows=None):
+    """render `frames` TraceRays calls on both sides; compare imageScratch + RGBA8 of the first `rows` image rows (all if
+    None: the reference kernel is launched for exactly those pixels)"""
+    w, h = dev.width, dev.height
+    n = w * (rows or h)
+    out = []
+    for f in range(frames):
+        ms = rs.ref.launch("k_ref_raygen", [rs.rtprop, rs.scratch, rs.image, rs.cam, rs.props, rs.meshInfo, rs.vertex, rs.index,
+                                            rs.uv, rs.normal, rs.material, rs.tlas, np.uint32(n)], n)
+        rs.set_rtprop(totalSamples=int(rs.rtprop_host[0]["totalSamples"]) + int(rs.rtprop_host[0]["batchSize"]))
+        img = dev.render()
+        st = rd.GetTraceStats()
+        a = rs.read_scratch()[: n * 4]
+        b = dev.read_scratch().reshape(-1)[: n * 4]
+        same = (a.view(np.uint32).reshape(-1, 4) == b.view(np.uint32).reshape(-1, 4)).all(1)
+        assert same.all(), "frame %d: %d of %d pixels differ (max |diff| %g)" % (f, int((~same).sum()), n, float(np.abs(a - b).max()))
+        assert np.array_equal(rs.read_image()[: n * 4], img.reshape(-1)[: n * 4])
+        out.append((ms, st.ms_total))
+    return out
+
+
+@pytest.mark.parametrize("cfg", ["c1_cornell", "c2_atrium"])
+def test_full_size_frames_identical_to_reference(mods, ref, cfg):
+    """BASELINE configs 1 and 2 at full size (1920x1080, 4 spp, depth 8): every pixel of imageScratch and of the RGBA8 image
+    equals the reference megakernel's, two progressive TraceRays calls (8.3 M paths, ~66 M rays each)"""
+    rd, scenes = mods
+    s = scenes.CONFIGS[cfg]()
+    dev = scenes.DeviceScene(s)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    rs = rg.RefScene(ref, s, blob)
+    t = _frames_identical(rd, dev, rs, frames=2)
+    print("%s: reference kernel %.0f ms, product %.1f ms per frame" % (cfg, t[0][0], t[0][1]))
+
+
+def test_c3_4k_64spp_identical_to_reference(mods, ref):
+    """BASELINE config 3 on one GPU: the Sponza-class scene at 3840x2160 with 64 spp (531 M paths in 34 sample chunks).  The
+    product renders the whole frame; the reference megakernel renders the first 36 image rows (138 k pixels x 64 spp =
+    8.8 M paths, what a whole 1080p x 4 spp frame costs it) and those pixels must be bit-identical -- the sample-chunk
+    boundaries and the running mean across 64 samples included"""
+    rd, scenes = mods
+    s = scenes.c2_atrium(3840, 2160, spp=64, depth=8)
+    dev = scenes.DeviceScene(s)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    rs = rg.RefScene(ref, s, blob)
+    _frames_identical(rd, dev, rs, frames=1, rows=36)
+    st = rd.GetTraceStats()
+    assert st.rays_primary == 3840 * 2160 * 64 and st.rays_shadow == st.closest_hits
+
+
+@pytest.fixture(scope="module")
+def c4(mods):
+    rd, scenes = mods
+    s = scenes.c4_atrium_10m(3840, 2160, spp=4, depth=8)
+    dev = scenes.DeviceScene(s)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    return s, dev, blob
+
+
+def test_c4_traversal_identical_to_reference_and_oracle(mods, ref, c4):
+    """BASELINE config 4 (10.4 M triangles + 64 instances of a shared foliage BLAS, 446 MB blob): 24 k primary and
+    scattered rays -- closest hit and any hit -- through the product's pool kernel, the reference's intersectTop on the
+    GPU and the CPU oracle walking the same product-built blob: HitData bit-identical three ways"""
+    rd, scenes = mods
+    s, dev, blob = c4
+    assert s.triangle_count() > 10_000_000 and len(s.instances) == 89
+    rs = rg.RefScene(ref, s, blob)
+    npix = s.width * s.height
+    sel = gc.spread(npix, 6000)
+    # primary rays of the selected pixels from the product's own generator (bit-identical to the reference's, see above)
+    po, pd = rd.GenerateBatch(sel.astype(np.uint32), gc.generate_inputs(sel.shape[0], 9))
+    ph = rd.TraceBatch(dev.topAccelStruct, po, pd)
+    o, d = gc.derived_rays(17, po, pd, ph["hit"], ph["distance"])
+    for rec in (1, 2):
+        r = rs.trace(o, d, 0.001, 1000.0, rec)
+        c = ob.trace_batch(blob, o, d, 0.001, 1000.0, rec)
+        _same_hits(r, c, closest=True, tag="oracle rec %d" % rec)          # the oracle keeps the reference's DFS order
+        for kernel in (3, 0):
+            rd.SetOption("kernel", kernel)
+            try:
+                g = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+            finally:
+                rd.SetOption("kernel", 3)
+            _same_hits(r, g, closest=(rec == 1), tag="kernel %d rec %d" % (kernel, rec))
+    assert (r["hit"] == 1).sum() > 8000
+
+
+def test_c4_progressive_frames_identical_to_reference(mods, ref, c4):
+    """config 4 at 3840x2160, progressive: three TraceRays calls of 4 spp with the host-side totalSamples += 4 of
+    samples/sample1.cpp:480-490 in between; the first 24 rows (92 k pixels) against the reference megakernel, bit for bit"""
+    rd, scenes = mods
+    s, dev, blob = c4
+    rs = rg.RefScene(ref, s, blob)
+    dev.set_rtprop(totalSamples=0); dev.clear_scratch()
+    _frames_identical(rd, dev, rs, frames=3, rows=24)
+    assert int(dev.rtprop["totalSamples"]) == 12
+
+
+def test_random_scenes_identical_to_reference(mods, ref):
+    """random meshes (incl. stacks of coincident triangles), up to 70 instances with random affine transforms, shear and
+    shared BLASes, rays from everywhere incl. axis-aligned ones: the product's kernels == the reference's intersectTop"""
+    import importlib.util
+    rd, scenes = mods
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    total = 0
+    for seed in range(700, 708):
+        s, o, d, rng = fz.random_case(seed)
+        dev = scenes.DeviceScene(s)
+        blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+        tl = rg.DevBuf.of(np.frombuffer(blob, np.uint8))
+        o, d = fz.with_surface_rays(rng, o, d, ref.trace(tl, o, d))
+        for rec in (1, 2):
+            r = ref.trace(tl, o, d, 0.001, 1000.0, rec)
+            for kernel in (3, 2, 1, 0):
+                rd.SetOption("kernel", kernel)
+                try:
+                    g = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+                finally:
+                    rd.SetOption("kernel", 3)
+                _same_hits(r, g, closest=(rec == 1), tag="seed %d kernel %d rec %d" % (seed, kernel, rec))
+        total += int((r["hit"] == 1).sum())
+    assert total > 2000

@@ -54,32 +54,42 @@ def rand_mesh(rng):
         return soup(rng, int(rng.integers(2, 40)))
     return scenes.cylinder([0, -1, 0], 0.5, 2.0, 12, 6, 0.05, int(rng.integers(0, 1000)))
 
+def random_case(seed):
+    """scene + first-stage rays of one seed (no GPU needed)"""
+    rng = np.random.default_rng(1000 + seed)
+    s = scenes.Scene("fuzz%d" % seed)
+    meshes = [s.add_mesh(rand_mesh(rng)) for _ in range(int(rng.integers(1, 7)))]
+    s.materials = [scenes.material((0.7, 0.7, 0.7))]
+    for _ in range(int(rng.integers(1, 71))):
+        s.add_instance(meshes[int(rng.integers(0, len(meshes)))], rand_tf(rng), 0)
+    s.camera = scenes.blender_camera(64, 48, 0.05, 0.036, 9.0, 0.0, (0.5, 14.0, 1.0), (-96.0, 180.0, 0.0))
+    s.sceneProps = scenes.blender_dir_light(-45.0, 20.0, 5.0)
+    s.rtprop = scenes._rtprop(0, 1, 2)
+    n = 6000
+    o = rng.uniform(-9, 9, (n, 3)).astype(F)
+    d = rng.normal(size=(n, 3)).astype(F); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tgt = rng.uniform(-6, 6, (n, 3)).astype(F)
+    d[: n // 2] = (tgt[: n // 2] - o[: n // 2]); d[: n // 2] /= np.linalg.norm(d[: n // 2], axis=1, keepdims=True)
+    ax = np.zeros((n // 6, 3), F); ax[np.arange(n // 6), rng.integers(0, 3, n // 6)] = rng.choice([-1.0, 1.0], n // 6)
+    d[-(n // 6):] = ax
+    return s, o, d, rng
+
+def with_surface_rays(rng, o, d, hits):
+    """append rays that start on the surfaces the first-stage rays hit"""
+    hp = (o + d * hits["distance"][:, None])[hits["hit"] == 1]
+    if hp.shape[0]:
+        d2 = rng.normal(size=hp.shape).astype(F); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        o = np.concatenate([o, hp.astype(F)]); d = np.concatenate([d, d2])
+    return np.ascontiguousarray(o, F), np.ascontiguousarray(d, F)
+
 def run(nseeds, first_seed=0, verbose=True):
     bad = 0
     fields = ("distance", "primitiveIndex", "instanceIndex", "instanceCustomIndex", "barycentric", "hitPoint", "transform")
     for seed in range(first_seed, first_seed + nseeds):
-        rng = np.random.default_rng(1000 + seed)
-        s = scenes.Scene("fuzz%d" % seed)
-        meshes = [s.add_mesh(rand_mesh(rng)) for _ in range(int(rng.integers(1, 7)))]
-        s.materials = [scenes.material((0.7, 0.7, 0.7))]
-        for _ in range(int(rng.integers(1, 71))):
-            s.add_instance(meshes[int(rng.integers(0, len(meshes)))], rand_tf(rng), 0)
-        s.camera = scenes.blender_camera(64, 48, 0.05, 0.036, 9.0, 0.0, (0.5, 14.0, 1.0), (-96.0, 180.0, 0.0))
-        s.sceneProps = scenes.blender_dir_light(-45.0, 20.0, 5.0)
-        s.rtprop = scenes._rtprop(0, 1, 2)
+        s, o, d, rng = random_case(seed)
         dev = scenes.DeviceScene(s)
-        n = 6000
-        o = rng.uniform(-9, 9, (n, 3)).astype(F)
-        d = rng.normal(size=(n, 3)).astype(F); d /= np.linalg.norm(d, axis=1, keepdims=True)
-        tgt = rng.uniform(-6, 6, (n, 3)).astype(F)
-        d[: n // 2] = (tgt[: n // 2] - o[: n // 2]); d[: n // 2] /= np.linalg.norm(d[: n // 2], axis=1, keepdims=True)
-        ax = np.zeros((n // 6, 3), F); ax[np.arange(n // 6), rng.integers(0, 3, n // 6)] = rng.choice([-1.0, 1.0], n // 6)
-        d[-(n // 6):] = ax
         ref = rd.TraceBatch(dev.topAccelStruct, o, d, reference_order=True)
-        hp = (o + d * ref["distance"][:, None])[ref["hit"] == 1]
-        if hp.shape[0]:                                   # rays starting on surfaces
-            d2 = rng.normal(size=hp.shape).astype(F); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
-            o = np.concatenate([o, hp.astype(F)]); d = np.concatenate([d, d2])
+        o, d = with_surface_rays(rng, o, d, ref)
         for rec in (1, 2):
             ref = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, reference_order=True)
             h = ref["hit"] == 1
