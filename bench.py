@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=-1, help="-1 library default; 2 cooperative, 3 cooperative with a shared node pool, 1 / 0 per-lane")
     ap.add_argument("--top-flat", type=int, default=-1, help="-1 library default; 0/1: evaluate small top-level trees all at once (pool engine)")
     ap.add_argument("--groups", type=int, default=-1, help="-1 library default; 1..4 sample groups of a chunk on their own streams")
+    ap.add_argument("--cull", type=int, default=-1, help="-1 library default (on); 0 = exhaustive walk, 1 = culled walk (pool engine)")
     ap.add_argument("--also", default="", help="comma list of extra workloads to time (reported under 'also')")
     args = ap.parse_args()
 
@@ -183,6 +184,8 @@ def main():
         rd.SetOption("top_flat", args.top_flat)
     if args.groups >= 1:
         rd.SetOption("groups", args.groups)
+    if args.cull >= 0:
+        rd.SetOption("cull", args.cull)
     if args.kernel >= 0:
         rd.SetOption("kernel", args.kernel)
         global ENGINE

@@ -167,7 +167,10 @@ int         rdx_set_profiling(int on);
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 3 = wave-
  * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
  * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
- * cross-checks), "top_flat" (1 (default) / 0: the pool kernel evaluates a top-level tree of <= 64 nodes all at once per
+ * cross-checks), "cull" (pool kernel: -1 (default) = automatic, 1 / 0 = on / off: closest-hit rays skip subtrees the ray enters
+ * beyond the best t found so far, every ray skips leaves whose box it misses -- with a 2^-8 relative margin; results are
+ * verified bit-identical to the reference's exhaustive walk, see kernels.hip "culled walk"; automatic = on for scenes with
+ * at least 16 k inner BVH nodes), "top_flat" (1 (default) / 0: the pool kernel evaluates a top-level tree of <= 64 nodes all at once per
  * ray instead of walking it), "inline_leaf_roots" (1 (default) / 0: ... and tests the triangles of single-leaf BLASes
  * right there), "pipeline" (0 = staged
  * wavefront: one launch per stage per bounce (default); 1 = whole paths -- camera ray to path end -- in one

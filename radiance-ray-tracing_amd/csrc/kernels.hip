@@ -183,6 +183,59 @@ __device__ __forceinline__ bool slab_fast(const RayInst& R, f3 bmin, f3 bmax)
     return slab_hit(R.o, R.d, a, b);        // inside the band (or non-finite): the reference's own form decides
 }
 
+// ---- culled walk (pool engine, option "cull") --------------------------------------------------------------------------
+// The reference's walk is exhaustive: it never compares a box with the best t found so far and never tests the box of a
+// leaf (radiance.cl:41-108,195-208).  Its RESULT, though, is the minimum of (t, instance slot, triangle slot) over the
+// triangles it tests and accepts (traverse_coop.h), and a triangle whose t cannot be smaller than the current best -- or
+// that the ray cannot touch at all -- never changes that minimum.  So, for a closest-hit ray, a subtree whose box the ray
+// enters beyond best_t, and for any ray a leaf whose box the ray misses, may be skipped.  In exact arithmetic that is
+// lossless; in fp32 the slab test and Moeller-Trumbore round differently, so both skips keep a margin of 2^-8 RELATIVE
+// (four orders of magnitude above the 2^-22 of the slab arithmetic; what it has to absorb is the error of a computed t or
+// barycentric of a badly conditioned -- grazing, sliver, far-away -- triangle).  This is not a proof: a triangle hit at
+// under ~0.1 degree whose computed t is off by more than 0.4 % could still be accepted by the reference and skipped here.
+// It is verified instead: bit-identical HitData and whole frames against the reference's own device code on every
+// config (tests/test_gpu_reference.py) and against the exhaustive kernels (options "cull" 0, "kernel" 2 / 1 / 0).
+#define RDX_CULL_K 1.00390625f            // 1 + 2^-8
+#define RDX_CULL_M 0.00390625f            // 2^-8
+
+// slab_fast that also reports the entry distance max(tNear, 0) its decision was made with
+__device__ __forceinline__ bool slab_fast_t(const RayInst& R, f3 bmin, f3 bmax, float& tn)
+{
+    if (!R.exactOnly) {
+        const f3 tA = (bmin - R.o) * R.rcp, tB = (bmax - R.o) * R.rcp;
+        const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
+        const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
+        const float n0 = fmaxf(tNear, 0.0f);
+        const float band = 4.8e-7f * (fabsf(tFar) + n0) + 1e-30f;
+        const float diff = tFar - n0;
+        tn = n0;
+        if (diff > band) return true;
+        if (diff < -band) return false;
+    }
+    // inside the band, or a (nearly) zero direction component: the reference's own form decides (radiance.cl:195-208)
+    const f3 tA = (bmin - R.o) / R.d, tB = (bmax - R.o) / R.d;
+    const f3 t1 = mk3(cl_min(tA.x, tB.x), cl_min(tA.y, tB.y), cl_min(tA.z, tB.z));
+    const f3 t2 = mk3(cl_max(tA.x, tB.x), cl_max(tA.y, tB.y), cl_max(tA.z, tB.z));
+    const float tNear = cl_max(cl_max(t1.x, t1.y), t1.z);
+    const float tFar = cl_min(cl_min(t2.x, t2.y), t2.z);
+    tn = cl_max(tNear, 0.0f);
+    return tFar > tn;
+}
+
+// may the ray touch a triangle inside this (leaf) box at a distance that still matters?  Conservative: `false` only when
+// the slabs miss each other by more than the margin, or the box is entered beyond cullT.  Rays with a (nearly) zero
+// direction component are never refused.
+__device__ __forceinline__ bool leaf_box_maybe(const RayInst& R, f3 bmin, f3 bmax, float cullT)
+{
+    if (R.exactOnly) return true;
+    const f3 tA = (bmin - R.o) * R.rcp, tB = (bmax - R.o) * R.rcp;
+    const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
+    const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
+    const float n0 = fmaxf(tNear, 0.0f);
+    const float m = RDX_CULL_M * (fabsf(tFar) + n0) + 1e-30f;
+    return !(n0 - tFar > m) && !(n0 > cullT);
+}
+
 struct Best {
     float t, b1, b2;
     uint32_t slot, inst;
@@ -808,25 +861,25 @@ k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
 }
 
 // ---- the same three launches on the shared-node-pool engine (traverse_pool.h, `kernel` option 3) ------------------------
-template <bool INL>
+template <bool INL, bool CULL>
 __global__ void COOP_BOUNDS
 k_extend_pool(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
 {
     ExtendPolicy pol{A, ps};
-    traverse_pool<1, INL>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<1, INL, CULL>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
-template <bool INL>
+template <bool INL, bool CULL>
 __global__ void COOP_BOUNDS
 k_shadow_pool(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
               uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
     const float* ld = sc.scene->lights[0].direction;
     ShadowPolicy pol{A, ps, normalize3(mk3(-ld[0], -ld[1], -ld[2])), lastBounce, nPixels, sampleBase};
-    traverse_pool<2, INL>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<2, INL, CULL>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
-template <bool INL>
+template <bool INL, bool CULL>
 __global__ void COOP_BOUNDS
 k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
              uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
@@ -835,7 +888,7 @@ k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
     const uint32_t m = *mPtr;
     FusedPolicy pol{ShadowPolicy{A, psShadow, normalize3(mk3(-ld[0], -ld[1], -ld[2])), 0u, nPixels, sampleBase},
                     ExtendPolicy{A, psExtend}, m};
-    traverse_pool<3, INL>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<3, INL, CULL>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -983,13 +1036,21 @@ k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __rest
     traverse_coop<REC>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
 }
 
-template <int REC, bool INL>
+template <bool INL, bool CULL>
 __global__ void COOP_BOUNDS
-k_trace_batch_pool(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
-                   float tmin, float tmax, rdx_hit* __restrict__ out)
+k_trace_batch_pool1(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
+                    float tmin, float tmax, rdx_hit* __restrict__ out)
 {
     BatchPolicy pol{A, o, d, out};
-    traverse_pool<REC, INL>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+    traverse_pool<1, INL, CULL>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+template <bool INL, bool CULL>
+__global__ void COOP_BOUNDS
+k_trace_batch_pool2(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
+                    float tmin, float tmax, rdx_hit* __restrict__ out)
+{
+    BatchPolicy pol{A, o, d, out};
+    traverse_pool<2, INL, CULL>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1140,8 +1201,14 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
     if (!nMax) return;
     if (!visit && av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
-        if (av.leafRoots) hipLaunchKernelGGL(k_extend_pool<true>, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
-        else hipLaunchKernelGGL(k_extend_pool<false>, dim3(coop_blocks(nMax, th, lds)), dim3(th), lds, st, av, ps, nPtr, counter, tmin, tmax);
+#define RDX_POOL_LAUNCH(K, GRID, ...)                                                                                         \
+        do {                                                                                                              \
+            if (av.leafRoots) { if (av.cull) hipLaunchKernelGGL((K<true, true>), GRID, dim3(th), lds, st, __VA_ARGS__);      \
+                                else hipLaunchKernelGGL((K<true, false>), GRID, dim3(th), lds, st, __VA_ARGS__); }          \
+            else { if (av.cull) hipLaunchKernelGGL((K<false, true>), GRID, dim3(th), lds, st, __VA_ARGS__);                 \
+                   else hipLaunchKernelGGL((K<false, false>), GRID, dim3(th), lds, st, __VA_ARGS__); }                      \
+        } while (0)
+        RDX_POOL_LAUNCH(k_extend_pool, dim3(coop_blocks(nMax, th, lds)), av, ps, nPtr, counter, tmin, tmax);
         return;
     }
     if (!visit && av.kernel == 2) {
@@ -1170,11 +1237,9 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
 {
     if (!nMax) return;
     if (!visit && av.kernel == 3) {
-        size_t ldsc; const uint32_t thc = pool_threads(av, ldsc);
-        if (av.leafRoots) hipLaunchKernelGGL(k_shadow_pool<true>, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
-                                             lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
-        else hipLaunchKernelGGL(k_shadow_pool<false>, dim3(coop_blocks(nMax, thc, ldsc)), dim3(thc), ldsc, st, av, sc, ps, nPtr, counter,
-                                lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
+        size_t lds; const uint32_t th = pool_threads(av, lds);
+        RDX_POOL_LAUNCH(k_shadow_pool, dim3(coop_blocks(nMax, th, lds)), av, sc, ps, nPtr, counter, lastBounce ? 1u : 0u, nPixels, sampleBase,
+                        tmin, tmax);
         return;
     }
     if (!visit && av.kernel == 2) {
@@ -1197,11 +1262,8 @@ void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
 {
     if (!mMax) return;
     if (av.kernel == 3) {
-        size_t ldsp; const uint32_t thp = pool_threads(av, ldsp);
-        if (av.leafRoots) hipLaunchKernelGGL(k_fused_pool<true>, dim3(coop_blocks(2u * mMax, thp, ldsp)), dim3(thp), ldsp, st, av, sc, psShadow, psExtend, mPtr,
-                                             counter, nPixels, sampleBase, tmin, tmax);
-        else hipLaunchKernelGGL(k_fused_pool<false>, dim3(coop_blocks(2u * mMax, thp, ldsp)), dim3(thp), ldsp, st, av, sc, psShadow, psExtend, mPtr,
-                                counter, nPixels, sampleBase, tmin, tmax);
+        size_t lds; const uint32_t th = pool_threads(av, lds);
+        RDX_POOL_LAUNCH(k_fused_pool, dim3(coop_blocks(2u * mMax, th, lds)), av, sc, psShadow, psExtend, mPtr, counter, nPixels, sampleBase, tmin, tmax);
         return;
     }
     size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
@@ -1251,15 +1313,10 @@ void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, con
 {
     if (!n) return;
     if (!visit && mode == 0 && av.kernel == 3) {
-        size_t ldsp; const uint32_t thp = pool_threads(av, ldsp);
-        const dim3 gp(coop_blocks(n, thp, ldsp));
-        if (av.leafRoots) {
-            if (rec == 2) hipLaunchKernelGGL((k_trace_batch_pool<2, true>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
-            else hipLaunchKernelGGL((k_trace_batch_pool<1, true>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
-        } else {
-            if (rec == 2) hipLaunchKernelGGL((k_trace_batch_pool<2, false>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
-            else hipLaunchKernelGGL((k_trace_batch_pool<1, false>), gp, dim3(thp), ldsp, st, av, o, d, n, counter, tmin, tmax, out);
-        }
+        size_t lds; const uint32_t th = pool_threads(av, lds);
+        const dim3 gp(coop_blocks(n, th, lds));
+        if (rec == 2) RDX_POOL_LAUNCH(k_trace_batch_pool2, gp, av, o, d, n, counter, tmin, tmax, out);
+        else RDX_POOL_LAUNCH(k_trace_batch_pool1, gp, av, o, d, n, counter, tmin, tmax, out);
         return;
     }
     if (!visit && mode == 0 && av.kernel == 2) {

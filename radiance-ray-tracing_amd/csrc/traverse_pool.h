@@ -60,7 +60,10 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
 // INL: the scene has instances whose BLAS is a single leaf of <= 8 triangles; they are handled inside the top-level step
 // (below).  A separate instantiation, chosen by the host per scene: the kernel sits at its register budget, and the extra
 // code costs scenes without such instances 10-15 % through spills even when it never runs.
-template <int REC, bool INL, class Policy>
+// CULL: the culled walk (kernels.hip "culled walk"): closest-hit rays skip subtrees entered beyond the best t so far and
+// push the nearer child on top; every ray skips leaves whose box it misses.  The push order then depends on the ray, so
+// A.blasNeed must be the any-order stack need (the host passes that one when the option is on).
+template <int REC, bool INL, bool CULL, class Policy>
 __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
                                               float tmin, float tmax, uint32_t* __restrict__ lds)
 {
@@ -342,7 +345,15 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                     POOL_TPOP();
                 } else {
                     const float4 rmin = ip[10], rmax = ip[11];
-                    if (slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z))) { rootNode = rdsc.x; pendN[lane] = 1u; tcur = POOL_INBLAS; }
+                    bool enter;
+                    if (CULL) {
+                        float tnRoot;
+                        enter = slab_fast_t(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z), tnRoot);
+                        const uint32_t hb = reinterpret_cast<const uint32_t*>(L.best)[2u * lane + 1u];
+                        if (!anyHit && hb != 0xffffffffu && tnRoot > __uint_as_float(hb) * RDX_CULL_K) enter = false;
+                        if (tnRoot > tmax * RDX_CULL_K) enter = false;
+                    } else enter = slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z));
+                    if (enter) { rootNode = rdsc.x; pendN[lane] = 1u; tcur = POOL_INBLAS; }
                     else POOL_TPOP();
                 }
             }
@@ -380,20 +391,36 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             int delta = 0;
             if (valid) {
                 delta = -1;
-                const bool dropIt = (REC != 1) && (qf & 4u) && L.best[wl] != ~0ull;      // shadow ray already answered
+                const uint32_t hb = reinterpret_cast<const uint32_t*>(L.best)[2u * wl + 1u];     // t bits of the owner's best candidate
+                const bool dropIt = (REC != 1) && (qf & 4u) && hb != 0xffffffffu;           // shadow ray already answered
                 if (!dropIt) {
                     const float4* wp = reinterpret_cast<const float4*>(A.wide + (item & POOL_NODE_MASK));
                     const float4 l0 = wp[0], l1 = wp[1], r0 = wp[2], r1 = wp[3];
                     const uint32_t ld0 = __float_as_uint(l0.w), ld1 = __float_as_uint(l1.w);
                     const uint32_t rd0 = __float_as_uint(r0.w), rd1 = __float_as_uint(r1.w);
-                    if (ld1 & WIDE_LEAF) { cntL = ld1 & 0x7fffffffu; stL = ld0; }
-                    else if (slab_fast(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z))) pushL = ld0;
-                    if (rd1 & WIDE_LEAF) { cntR = rd1 & 0x7fffffffu; stR = rd0; }
-                    else if (slab_fast(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z))) pushR = rd0;
+                    if (CULL) {
+                        float cullT = tmax * RDX_CULL_K;
+                        if (((REC == 1) || !(qf & 4u)) && hb != 0xffffffffu) cullT = fminf(cullT, __uint_as_float(hb) * RDX_CULL_K);
+                        float tnL = 0.f, tnR = 0.f;
+                        if (ld1 & WIDE_LEAF) {
+                            if (leaf_box_maybe(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), cullT)) { cntL = ld1 & 0x7fffffffu; stL = ld0; }
+                        } else if (slab_fast_t(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), tnL) && !(tnL > cullT)) pushL = ld0;
+                        if (rd1 & WIDE_LEAF) {
+                            if (leaf_box_maybe(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), cullT)) { cntR = rd1 & 0x7fffffffu; stR = rd0; }
+                        } else if (slab_fast_t(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), tnR) && !(tnR > cullT)) pushR = rd0;
+                        // the nearer child goes on top of the LIFO (the "L" slot is written above the "R" slot below)
+                        if (pushL != COOP_NONE && pushR != COOP_NONE && tnL > tnR) { const uint32_t t_ = pushL; pushL = pushR; pushR = t_; }
+                    } else {
+                        if (ld1 & WIDE_LEAF) { cntL = ld1 & 0x7fffffffu; stL = ld0; }
+                        else if (slab_fast(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z))) pushL = ld0;
+                        if (rd1 & WIDE_LEAF) { cntR = rd1 & 0x7fffffffu; stR = rd0; }
+                        else if (slab_fast(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z))) pushR = rd0;
+                    }
                     delta += (pushL != COOP_NONE ? 1 : 0) + (pushR != COOP_NONE ? 1 : 0);
                 }
             }
             {   // right children below left ones: the left half of a wide node holds the subtree with the smaller stack need
+                // (CULL: the nearer child on top instead; the pool is then sized for any order)
                 const unsigned long long mR = __ballot(pushR != COOP_NONE), mL = __ballot(pushL != COOP_NONE);
                 const uint32_t nR = (uint32_t)__popcll(mR);
                 if (pushR != COOP_NONE) pool[poolTop + lanes_below(mR)] = (wl << POOL_LANE_SHIFT) | (pushR & POOL_NODE_MASK);

@@ -12,6 +12,8 @@ KINDS = ["finish/refill", "shade", "steal", "leaf item", "top", "instance", "nod
 L = _lib.lib()
 fn = L.rdx_debug_coop_stats
 fn.restype = ctypes.c_int
+if os.environ.get("RDX_CULL"):
+    rd.SetOption("cull", int(os.environ["RDX_CULL"]))
 for cfg, w, h in (("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_cornell", 680, 381)):
     s = scenes.CONFIGS[cfg](w, h, 4, 8)
     dev = scenes.DeviceScene(s)
