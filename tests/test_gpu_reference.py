@@ -87,14 +87,14 @@ def test_product_matches_reference_goldens(mods, name):
     ref_h = np.ascontiguousarray(G["hits"]).view(ob.HIT_DTYPE).reshape(-1)
     o, d = G["ray_o"], G["ray_d"]
     _same_hits(ref_h, rd.TraceBatch(dev.topAccelStruct, o, d, reference_order=True), tag="reference-order kernel")
-    for kernel in (3, 2, 1):
-        rd.SetOption("kernel", kernel)
+    for kernel, cull in ((3, 1), (3, 0), (2, 0), (1, 0)):      # pool engine with the culled and the exhaustive walk, ...
+        rd.SetOption("kernel", kernel); rd.SetOption("cull", cull)
         try:
-            _same_hits(ref_h, rd.TraceBatch(dev.topAccelStruct, o, d), tag="kernel %d" % kernel)
+            _same_hits(ref_h, rd.TraceBatch(dev.topAccelStruct, o, d), tag="kernel %d cull %d" % (kernel, cull))
             sh = rd.TraceBatch(dev.topAccelStruct, o, d, sbtRecordOffset=2)
         finally:
-            rd.SetOption("kernel", 3)
-        assert np.array_equal(sh["hit"].astype(np.uint8), G["shadow_hit"]), kernel
+            rd.SetOption("kernel", 3); rd.SetOption("cull", -1)
+        assert np.array_equal(sh["hit"].astype(np.uint8), G["shadow_hit"]), (kernel, cull)
     assert (ref_h["hit"] == 1).sum() > 500
     # primary rays: generateRay of every pixel (pinhole; thin lens for c1)
     npix = s.width * s.height
@@ -109,11 +109,17 @@ def test_product_matches_reference_goldens(mods, name):
     got = rd.MaterialBatch(hits, G["mat_dir"], np.arange(n, dtype=np.uint32), frames, depths)
     lit, occ = _check_material(s, hits, ref_pay, got)
     assert lit > 100
-    # two progressive frames: imageScratch and RGBA8 bit for bit
-    for f in range(2):
-        img = dev.render()
-        assert np.array_equal(_bits(dev.read_scratch().reshape(-1)), _bits(G["scratch%d" % f])), f
-        assert np.array_equal(img.reshape(-1), G["image%d" % f]), f
+    # two progressive frames: imageScratch and RGBA8 bit for bit, with the culled and with the exhaustive walk
+    for cull in (1, 0):
+        rd.SetOption("cull", cull)
+        try:
+            dev.set_rtprop(totalSamples=0); dev.clear_scratch()
+            for f in range(2):
+                img = dev.render()
+                assert np.array_equal(_bits(dev.read_scratch().reshape(-1)), _bits(G["scratch%d" % f])), (cull, f)
+                assert np.array_equal(img.reshape(-1), G["image%d" % f]), (cull, f)
+        finally:
+            rd.SetOption("cull", -1)
     if name == "c1":
         dev2 = scenes.DeviceScene(gc.small_scene(scenes, name, fstop=2.8))
         lo, ld = rd.GenerateBatch(px, G["gen_rnd"])
@@ -145,16 +151,21 @@ def _frames_identical(rd, dev, rs, frames=1, rows=None):
     return out
 
 
-@pytest.mark.parametrize("cfg", ["c1_cornell", "c2_atrium"])
-def test_full_size_frames_identical_to_reference(mods, ref, cfg):
+@pytest.mark.parametrize("cfg,cull", [("c1_cornell", 1), ("c1_cornell", 0), ("c2_atrium", 1), ("c2_atrium", 0)])
+def test_full_size_frames_identical_to_reference(mods, ref, cfg, cull):
     """BASELINE configs 1 and 2 at full size (1920x1080, 4 spp, depth 8): every pixel of imageScratch and of the RGBA8 image
-    equals the reference megakernel's, two progressive TraceRays calls (8.3 M paths, ~66 M rays each)"""
+    equals the reference megakernel's, two progressive TraceRays calls (8.3 M paths, ~66 M rays each); culled and
+    exhaustive walk"""
     rd, scenes = mods
     s = scenes.CONFIGS[cfg]()
     dev = scenes.DeviceScene(s)
     blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
     rs = rg.RefScene(ref, s, blob)
-    t = _frames_identical(rd, dev, rs, frames=2)
+    rd.SetOption("cull", cull)
+    try:
+        t = _frames_identical(rd, dev, rs, frames=2)
+    finally:
+        rd.SetOption("cull", -1)
     print("%s: reference kernel %.0f ms, product %.1f ms per frame" % (cfg, t[0][0], t[0][1]))
 
 
@@ -230,7 +241,7 @@ def test_random_scenes_identical_to_reference(mods, ref):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     total = 0
-    for seed in range(700, 708):
+    for seed in range(700, 724):
         s, o, d, rng = fz.random_case(seed)
         dev = scenes.DeviceScene(s)
         blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
@@ -238,12 +249,12 @@ def test_random_scenes_identical_to_reference(mods, ref):
         o, d = fz.with_surface_rays(rng, o, d, ref.trace(tl, o, d))
         for rec in (1, 2):
             r = ref.trace(tl, o, d, 0.001, 1000.0, rec)
-            for kernel in (3, 2, 1, 0):
-                rd.SetOption("kernel", kernel)
+            for kernel, cull in ((3, 1), (3, 0), (2, 0), (1, 0), (0, 0)):
+                rd.SetOption("kernel", kernel); rd.SetOption("cull", cull)
                 try:
                     g = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
                 finally:
-                    rd.SetOption("kernel", 3)
-                _same_hits(r, g, closest=(rec == 1), tag="seed %d kernel %d rec %d" % (seed, kernel, rec))
+                    rd.SetOption("kernel", 3); rd.SetOption("cull", -1)
+                _same_hits(r, g, closest=(rec == 1), tag="seed %d kernel %d cull %d rec %d" % (seed, kernel, cull, rec))
         total += int((r["hit"] == 1).sum())
     assert total > 2000

@@ -93,16 +93,16 @@ def run(nseeds, first_seed=0, verbose=True):
         for rec in (1, 2):
             ref = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, reference_order=True)
             h = ref["hit"] == 1
-            for kernel in (3, 2, 1):
-                rd.SetOption("kernel", kernel)
+            for kernel, cull in ((3, 1), (3, 0), (2, 0), (1, 0)):
+                rd.SetOption("kernel", kernel); rd.SetOption("cull", cull)
                 got = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
-                rd.SetOption("kernel", 3)
+                rd.SetOption("kernel", 3); rd.SetOption("cull", -1)
                 ok = np.array_equal(ref["hit"], got["hit"])
                 if ok and rec == 1:
                     ok = all(np.array_equal(ref[f][h].view(np.uint8), got[f][h].view(np.uint8)) for f in fields)
                 if not ok:
                     bad += 1
-                    print("MISMATCH seed %d rec %d kernel %d (%d instances, %d rays, %d hits)" % (seed, rec, kernel, len(s.instances), o.shape[0], int(h.sum())), flush=True)
+                    print("MISMATCH seed %d rec %d kernel %d cull %d (%d instances, %d rays, %d hits)" % (seed, rec, kernel, cull, len(s.instances), o.shape[0], int(h.sum())), flush=True)
         if verbose and seed % 10 == 9:
             print("seed %d done, %d instances, %d rays, %d hits, mismatches so far %d" % (seed, len(s.instances), o.shape[0], int(h.sum()), bad), flush=True)
     return bad
