@@ -28,6 +28,19 @@ def per_kernel(path, counter):
     return {k: {"launches": v[0], "avg_KiB_per_launch": v[1] / v[0]} for k, v in agg.items()}
 
 
+def per_kernel_all(path):
+    """{kernel: {counter: average per launch}} for every counter of one pass"""
+    if not os.path.exists(path):
+        return {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen[k].add(r.get("Dispatch_Id"))
+    return {k: dict({c: v / max(1, len(seen[k])) for c, v in d.items()}, launches=len(seen[k])) for k, d in agg.items() if k.startswith("rdx::")}
+
+
 def main():
     prof, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     workload = sys.argv[4] if len(sys.argv) > 4 else "sample1"
@@ -56,6 +69,30 @@ def main():
         json.dump({"workload": workload, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled "
                            "per the gfx950 calibration for wide coalesced reads (uncalibrated for other widths)",
                    "kernels": summ}, fjs, indent=1)
+    # instruction-issue and cache counters (separate passes), averages per launch
+    extra = {}
+    for name in ("issue", "cache"):
+        f = os.path.join(prof, name, "r1_counter_collection.csv")
+        d = per_kernel_all(f)
+        if d:
+            for k, v in d.items():
+                if "SQ_INSTS_VALU" in v and v["SQ_INSTS_VALU"]:
+                    v["active_lanes_per_valu_inst"] = v.get("SQ_THREAD_CYCLES_VALU", 0.0) / v["SQ_INSTS_VALU"]
+                    v["salu_per_valu"] = v.get("SQ_INSTS_SALU", 0.0) / v["SQ_INSTS_VALU"]
+                    if v.get("GRBM_GUI_ACTIVE"):
+                        v["valu_issue_frac_of_pass_cycles"] = v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0)
+                    if v.get("SQ_WAVE_CYCLES"):
+                        v["wave_cycles_parked_frac"] = v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]
+                if v.get("TCC_HIT_sum") is not None and (v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0)):
+                    v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+                if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                    v["l1_hit_rate"] = 1.0 - v.get("TCP_TCC_READ_REQ_sum", 0.0) / v["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            extra[name] = d
+    if extra:
+        with open(os.path.join(out, "%s_pmc_issue.json" % tag), "w") as fjs:
+            json.dump({"workload": workload, "note": "rocprofv3 --pmc, one pass per group, averages per launch; valu_issue_frac = "
+                       "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) of the PMC pass itself",
+                       "passes": extra}, fjs, indent=1)
     print(json.dumps(summ, indent=1))
 
 
