@@ -21,9 +21,17 @@ struct AccelView {                 // derived traversal layout (see rdx_types.h)
     uint32_t topNeed, blasNeed;    // its top-level / per-BLAS parts (pool engine: private top-level stacks + shared node pool)
     uint32_t leafRoots;            // pool engine: the scene has single-leaf BLASes handled in the flat top-level step (needs topFlat)
     uint32_t topFlat;              // pool engine: > 0 = number of top-level nodes, evaluated all at once per ray (<= 64 nodes)
+    uint32_t* status;              // device-visible status word (pinned host memory): bit 0 = a traversal wave hit its iteration bound
     uint32_t cull;                 // pool engine: culled walk (best-t culling of closest-hit rays, leaf-box test; kernels.hip)
     uint32_t kernel;               // 2 = wave-cooperative (default), 3 = wave-cooperative with a shared node pool, 1 = per-lane wide, 0 = reference order
 };
+
+// limits of the cooperative engines' packed words, shared by the kernels (traverse_coop.h) and the host's fallback rule
+constexpr uint32_t RDX_COOP_MAX_TRI_SLOTS = 1u << 25;    // queue entry: lane << 26 | parity << 25 | absolute triangle slot
+constexpr uint32_t RDX_COOP_MAX_WIDE = 1u << 26;         // pool item: lane << 26 | wide-node index
+constexpr uint32_t RDX_COOP_MAX_INSTANCES = 1u << 10;    // key: instance slot << 22 | BLAS-local triangle slot
+constexpr uint32_t RDX_COOP_MAX_BLAS_TRIS = 1u << 22;
+constexpr uint32_t RDX_LDS_WORDS_PER_WAVE_MAX = 16384u;  // 64 KB per workgroup of one wave
 
 struct SceneArgs {                 // descriptor slots 4-10 (samples/shader.cl:175-190)
     const SceneProperties* scene;
@@ -63,6 +71,10 @@ struct PathStreams {
     float4* colSh;     // colour if it is occluded
     float4* sampleColor; // [samples_in_chunk][pixels] final per-sample radiance
 };
+
+// LDS words one wave of the cooperative / pool engine needs for the given stack needs (traverse_coop.h, traverse_pool.h)
+uint32_t coop_lds_words(uint32_t coopNeed);
+uint32_t pool_lds_words(uint32_t topNeed, uint32_t blasNeed);
 
 // how many persistent traversal launches are to share the GPU from now on (sample groups on their own streams):
 // each launch takes 1/groups of the resident grid.  Host state, set by rdx_trace_rays per chunk.

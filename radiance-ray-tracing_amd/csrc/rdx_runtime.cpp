@@ -107,6 +107,8 @@ struct Context {
     size_t sampleCap = 0;
     float4* sampleColor = nullptr;
     uint32_t* dCounts = nullptr;            // = groups[0].dCounts (test seams)
+    uint32_t* hStatus = nullptr;            // pinned, device-mapped: bit 0 = a traversal wave hit its iteration bound
+    uint32_t* dStatus = nullptr;            // its device address
     int groupsOpt = 0;                      // sample groups in flight: 1..4, 0 = two for chunks small enough to be ramp + drain bound
     int fuse = -1;                          // shadow(d) + extend(d+1) in one launch: 1 / -1 on, 0 off
     int pathMode = 0;                       // 0 = staged wavefront (launch per stage per bounce), 1 = whole paths in one launch
@@ -187,17 +189,30 @@ int derive_accel(rdx_buffer_s* tb)
         if (tnodes[i].w0 & LEAF_BIT) nInst = std::max(nInst, tnodes[i].w1 + (tnodes[i].w0 & 0x7fffffffu));
     if ((size_t)th->instByteOffset + (size_t)nInst * sizeof(BlobInst) > bsz) return fail("TLAS blob: instance array out of range");
 
+    // The derived layout (stack needs computed children-first, first-in-DFS tie-break = lowest slot) relies on the numbering
+    // the reference's flattener produces (bvh.cpp:475-497,551-563): DFS pre-order -- left child = parent + 1, right child
+    // behind the whole left subtree -- and leaves listing their instances / triangles in leaf order.  A foreign or
+    // corrupted blob (e.g. a cache file without side-car) that breaks it is refused here rather than mis-sized on the GPU.
     std::vector<DNode> dT(nTop);
-    for (uint32_t i = 0; i < nTop; ++i) {
-        std::memcpy(&dT[i], &tnodes[i], sizeof(BlobNode));
-        if (!(tnodes[i].w0 & LEAF_BIT) && (tnodes[i].w0 >= nTop || tnodes[i].w1 >= nTop)) return fail("TLAS blob: child index out of range");
+    {
+        uint32_t expectInst = 0;
+        for (uint32_t i = 0; i < nTop; ++i) {
+            std::memcpy(&dT[i], &tnodes[i], sizeof(BlobNode));
+            if (!(tnodes[i].w0 & LEAF_BIT)) {
+                if (tnodes[i].w0 >= nTop || tnodes[i].w1 >= nTop) return fail("TLAS blob: child index out of range");
+                if (tnodes[i].w0 != i + 1 || tnodes[i].w1 <= tnodes[i].w0) return fail("TLAS blob: node %u is not in DFS pre-order (children %u, %u)", i, tnodes[i].w0, tnodes[i].w1);
+            } else {
+                if (tnodes[i].w1 != expectInst) return fail("TLAS blob: leaf %u does not list its instances in leaf order (start %u, expected %u)", i, tnodes[i].w1, expectInst);
+                expectInst += tnodes[i].w0 & 0x7fffffffu;
+            }
+        }
     }
     std::vector<DNode> dB;
     std::vector<DTri> dTri;
     std::vector<DWide> dW;
     std::vector<DInst> dI(nInst);
     struct BlasInfo { uint32_t nodeBase; uint32_t need; uint32_t coopNeed; uint32_t anyNeed; uint32_t triBase; uint32_t rootDesc0, rootDesc1; float rootMin[3], rootMax[3]; };
-    bool coopOK = nInst <= 1024;
+    bool coopOK = nInst <= RDX_COOP_MAX_INSTANCES;
     uint32_t maxLeafChunks = 0;             // extra stack entries an oversized (> 8 triangle) leaf can push
     uint32_t maxLeafTris = 0;
     std::map<uint32_t, BlasInfo> blasAt;    // byte offset -> merged-array base
@@ -222,16 +237,22 @@ int derive_accel(rdx_buffer_s* tb)
             const uint32_t nodeBase = (uint32_t)dB.size(), triBase = (uint32_t)dTri.size();
             if ((uint64_t)nodeBase + nNodes >= (1u << 30)) return fail("too many BVH nodes for 30-bit references");
             dB.resize(nodeBase + nNodes);
+            uint32_t expectTri = 0;
             for (uint32_t i = 0; i < nNodes; ++i) {
                 DNode& d = dB[nodeBase + i];
                 std::memcpy(&d, &bn[i], sizeof(BlobNode));
                 if (bn[i].w0 & LEAF_BIT) {
                     if ((uint64_t)bn[i].w1 + (bn[i].w0 & 0x7fffffffu) > nTris) return fail("BLAS blob: leaf range out of bounds");
+                    if (bn[i].w2 == TYPE_TRIG) {
+                        if (bn[i].w1 != expectTri) return fail("BLAS blob: leaf %u does not list its triangles in leaf order (start %u, expected %u)", i, bn[i].w1, expectTri);
+                        expectTri += bn[i].w0 & 0x7fffffffu;
+                    }
                     maxLeafChunks = std::max(maxLeafChunks, 2u * (((bn[i].w0 & 0x7fffffffu) + 7u) / 8u));
                     maxLeafTris = std::max(maxLeafTris, bn[i].w0 & 0x7fffffffu);
                     d.w1 = bn[i].w1 + triBase;
                 } else {
                     if (bn[i].w0 >= nNodes || bn[i].w1 >= nNodes) return fail("BLAS blob: child index out of range");
+                    if (bn[i].w0 != i + 1 || bn[i].w1 <= bn[i].w0) return fail("BLAS blob: node %u is not in DFS pre-order (children %u, %u)", i, bn[i].w0, bn[i].w1);
                     d.w0 = bn[i].w0 + nodeBase; d.w1 = bn[i].w1 + nodeBase;
                 }
             }
@@ -285,7 +306,7 @@ int derive_accel(rdx_buffer_s* tb)
             }
             BlasInfo info{};
             info.nodeBase = nodeBase; info.need = std::max(blas_need(bn, 0), wneed[0]); info.coopNeed = cneed[0]; info.anyNeed = aneed[0]; info.triBase = triBase;
-            if (nTris > (1u << 22)) coopOK = false;
+            if (nTris > RDX_COOP_MAX_BLAS_TRIS) coopOK = false;
             desc(0, info.rootDesc0, info.rootDesc1);
             for (int k = 0; k < 3; ++k) { info.rootMin[k] = bn[0].bottom[k]; info.rootMax[k] = bn[0].top[k]; }
             it = blasAt.emplace(bi.instanceOffset, info).first;
@@ -375,7 +396,8 @@ int derive_accel(rdx_buffer_s* tb)
     ac->blasNeed = maxBlasCoop;
     ac->blasNeedAny = maxBlasAny;
     ac->nWide = (uint32_t)dW.size();
-    if (ac->stackNeed > 2560) return fail("BVH too deep for the LDS traversal stack (%u entries)", ac->stackNeed);
+    // per-lane kernels: [need][64 lanes] words of LDS per wave, 64 KB at most
+    if (ac->stackNeed > 250) return fail("BVH too deep for the LDS traversal stack: %u entries per ray needed, 250 available", ac->stackNeed);
     auto up = [&](auto*& dptr, const auto& vec) -> hipError_t {
         using T = typename std::remove_reference<decltype(vec)>::type::value_type;
         const size_t bytes = std::max<size_t>(vec.size(), 1) * sizeof(T);
@@ -389,7 +411,10 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->bnodes, dB));
     HIP_OK(up(ac->tris, dTri));
     HIP_OK(up(ac->wide, dW));
-    ac->coopOK = coopOK && dTri.size() < (1u << 26) && dW.size() < (1u << 26);      // (pool items carry a 26-bit wide-node index)
+    // packed-word limits of the cooperative engines (kernels.h) and their LDS footprint; beyond them the per-lane wide kernel runs
+    ac->coopOK = coopOK && dTri.size() <= RDX_COOP_MAX_TRI_SLOTS - 1u && dW.size() < RDX_COOP_MAX_WIDE &&
+                 coop_lds_words(ac->coopNeed) <= RDX_LDS_WORDS_PER_WAVE_MAX &&
+                 pool_lds_words(std::max(ac->topNeed, ac->topFlatNeed), std::max(ac->blasNeed, ac->blasNeedAny)) <= RDX_LDS_WORDS_PER_WAVE_MAX;
     if (std::getenv("RDX_VERBOSE"))
         std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u = top %u + BLAS %u)\n",
                      nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed, ac->topNeed, ac->blasNeed);
@@ -404,6 +429,7 @@ AccelView view_of(const rdx_buffer_s* tb)
     AccelView v{};
     v.tnodes = tb->accel->tnodes; v.ctnodes = tb->accel->ctnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
     v.wide = tb->accel->wide;
+    v.status = g.dStatus;
     v.kernel = (g.kernel >= 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
     v.stackNeed = tb->accel->stackNeed;
     v.coopNeed = tb->accel->coopNeed;
@@ -572,6 +598,9 @@ extern "C" int rdx_init(int device)
         HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&G.hCounts), 256 * sizeof(uint32_t), hipHostMallocDefault));
     }
     g.dCounts = g.groups[0].dCounts;
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hStatus), 64, hipHostMallocMapped));
+    *g.hStatus = 0;
+    HIP_OK(hipHostGetDevicePointer(reinterpret_cast<void**>(&g.dStatus), g.hStatus, 0));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&g.dVisit), 64 * 8 * sizeof(unsigned long long)));     // [bounce][class*4 + kind]
     HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&g.hVisit), 64 * 8 * sizeof(unsigned long long), hipHostMallocDefault));
     g.initialized = true;
@@ -599,6 +628,8 @@ extern "C" int rdx_shutdown(void)
     }
     if (g.sampleColor) HIP_IGN(hipFree(g.sampleColor));
     if (g.ownedPixels) HIP_IGN(hipFree(g.ownedPixels));
+    if (g.hStatus) HIP_IGN(hipHostFree(g.hStatus));
+    g.hStatus = nullptr; g.dStatus = nullptr;
     if (g.dVisit) HIP_IGN(hipFree(g.dVisit));
     if (g.hVisit) HIP_IGN(hipHostFree(g.hVisit));
     HIP_IGN(hipEventDestroy(g.evA)); HIP_IGN(hipEventDestroy(g.evB)); HIP_IGN(hipEventDestroy(g.evChunk));
@@ -1202,6 +1233,10 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
     if (visit) HIP_OK(hipMemcpyAsync(g.hVisit, g.dVisit, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));          // clFinish (radiance.cpp:261)
+    if (g.hStatus && *g.hStatus) {
+        *g.hStatus = 0;
+        return fail("TraceRays: a traversal wave exceeded its iteration bound and gave up (internal error in the step selection); the frame is incomplete");
+    }
     HIP_OK(hipEventElapsedTime(&g.stats.ms_total, g.evA, g.evB));
     g_timer.resolve();
     g.visitDepth = 0;

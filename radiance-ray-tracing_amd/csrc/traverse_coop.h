@@ -67,8 +67,10 @@ static_assert(COOP_QCAP >= 512u && (COOP_QCAP & (COOP_QCAP - 1u)) == 0u, "queue 
 #define COOP_LANE_SHIFT 26u            // queue entry = walking lane << 26 | instance parity << 25 | absolute triangle slot
 #define COOP_PAR_SHIFT 25u
 #define COOP_SLOT_MASK ((1u << 25) - 1u)
+static_assert(COOP_SLOT_MASK + 1u == RDX_COOP_MAX_TRI_SLOTS, "the host's fallback rule (derive_accel) must match the queue entry layout");
 #define COOP_INST_SHIFT 22u            // key low word = instance slot << 22 | BLAS-local triangle slot
 #define COOP_LOCAL_MASK ((1u << 22) - 1u)
+static_assert((1u << COOP_INST_SHIFT) == RDX_COOP_MAX_BLAS_TRIS && (RDX_COOP_MAX_INSTANCES << COOP_INST_SHIFT) == 0u, "key layout");
 #define COOP_NONE 0xffffffffu
 #define COOP_RAY_WORDS 7u              // per lane: o.xyz d.xyz (object space), instance slot | owner lane << 16 of the instance being left
 #ifndef COOP_IDLE_BIAS

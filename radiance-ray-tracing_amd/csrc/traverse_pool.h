@@ -53,6 +53,9 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
 #ifndef POOL_W_INST
 #define POOL_W_INST 12
 #endif
+#ifndef POOL_MAX_ITER
+#define POOL_MAX_ITER (1u << 24)       // iterations of one wave before it gives up (a full 1080p frame needs ~1e5 per wave)
+#endif
 #ifndef POOL_IDLE_MIN
 #define POOL_IDLE_MIN 32               // finished / free lanes a hand-over step waits for (16: +13 %, 24: +4 %, 40-48: +0-3 % frame time)
 #endif
@@ -105,18 +108,17 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         tcur = (WALK) ? (TAG_TLAS | 0u) : COOP_NONE;                                                   \
     } while (0)
 
-#if COOP_WATCHDOG
+    // Bounded loop: the step selection below is meant to make progress on every iteration; should a logic error ever break
+    // that, the wave leaves after POOL_MAX_ITER iterations and raises the status word the host checks after the frame
+    // (rdx_trace_rays then returns an error) instead of hanging the GPU.  One scalar add + compare per iteration.
     uint32_t iter = 0;
-#endif
 #ifdef COOP_STATS
     uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // as traverse_coop.h; kind 6 = pool step
     uint32_t stState[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (;;) {
-#if COOP_WATCHDOG
         iter = __builtin_amdgcn_readfirstlane(iter + 1u);
-        if (iter > COOP_MAX_ITER) break;
-#endif
+        if (iter > POOL_MAX_ITER) { if (lane == 0 && A.status) atomicOr(A.status, 1u); break; }
         // a lane whose instance has left the pool moves on along its top-level stack
         if (tcur == POOL_INBLAS && pendN[lane] == 0u) POOL_TPOP();
         if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }

@@ -111,8 +111,15 @@ class FrameSharder:
         self.tile_w, self.tile_h = tile_w, tile_h
         self.max_tiles = max_owned_tiles(world, width, height, tile_w, tile_h)
         n = self.max_tiles * tile_w * tile_h * 4
-        self.packed = torch.zeros(n, dtype=torch.uint8, device=device)
-        self.packed_buf = rd.WrapDeviceMemory(plt, self.packed.data_ptr(), n, self.packed)
+        # Two staging buffers, used alternately, each with an event recorded behind its gather: with the nccl backend
+        # dist.gather only enqueues the send (torch's current stream waits for RCCL's stream, the host does not), while
+        # rdx_pack_tiles runs on the library's own stream -- so before a buffer is packed again the host waits for the
+        # event of the frame that last sent it (two frames ago: by then it has long completed), and a pending send can
+        # never read the next frame's tiles.
+        self.packed = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.packed_buf = [rd.WrapDeviceMemory(plt, t.data_ptr(), n, t) for t in self.packed]
+        self.sent = [None, None]
+        self.frame = 0
         self.recv, self.recv_bufs = None, None
         if rank == 0 and world > 1:
             self.recv = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(world)]
@@ -126,9 +133,17 @@ class FrameSharder:
         if self.world == 1:
             return
         L, rd = _lib.lib(), self.rd
-        if L.rdx_pack_tiles(image_buffer.handle, self.packed_buf.handle, self.width, self.height, 4, self.rank, self.world):
+        b = self.frame & 1
+        self.frame += 1
+        if self.sent[b] is not None:
+            self.sent[b].synchronize()          # the send that last read this buffer has completed
+        if L.rdx_pack_tiles(image_buffer.handle, self.packed_buf[b].handle, self.width, self.height, 4, self.rank, self.world):
             raise rd.RadianceError(_lib.last_error())
-        gather_to_root(self.packed, self.world, 0, self.recv)
+        gather_to_root(self.packed[b], self.world, 0, self.recv)
+        if self.packed[b].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()                         # on torch's current stream, which dist.gather made wait for the collective
+            self.sent[b] = ev
         if self.rank == 0:
             torch.cuda.synchronize()
             import ctypes as C

@@ -614,3 +614,72 @@ def test_large_and_walked_top_level_trees(mods):
                 assert ref["hit"].sum() > 1000
         finally:
             rd.SetOption("top_flat", 1)
+
+
+def test_foreign_blob_is_refused(mods):
+    """a TLAS blob whose nodes are not in the reference's DFS pre-order (a foreign or corrupted cache file) is refused with a
+    clear error at first use instead of being mis-sized on the GPU"""
+    rd, scenes = mods
+    s = scenes.c1_cornell(32, 18, sphere_subdiv=2)
+    dev = scenes.DeviceScene(s)
+    blob = bytearray(rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes())
+    words = np.frombuffer(blob, np.uint32).copy()
+    # top-level root = node 0 at byte 16: words 4..15; children in words 12, 13 -> swap them
+    assert not (words[12] & 0x80000000)
+    words[12], words[13] = words[13], words[12]
+    rd.WriteBuffer(dev.plt, dev.topAccelStruct, words.nbytes, words.view(np.uint8))
+    with pytest.raises(rd.RadianceError, match="DFS pre-order"):
+        rd.TraceRays(dev.plt, 0, 0, 0, 32, 18)
+    words[12], words[13] = words[13], words[12]
+    rd.WriteBuffer(dev.plt, dev.topAccelStruct, words.nbytes, words.view(np.uint8))
+    rd.TraceRays(dev.plt, 0, 0, 0, 32, 18)
+
+
+def _shard_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank); os.environ["WORLD_SIZE"] = str(world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import torch
+    import torch.distributed as tdist
+    import rrt_amd  # noqa: F401
+    from radiance_ray_tracing_amd import dist as rdist, rd, scenes
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    plt = rd.Platform.GetPlatform(0)
+    W, H = 200, 120
+    s = scenes.c1_cornell(W, H, spp=1, depth=3, sphere_subdiv=2)
+    dev = scenes.DeviceScene(s, plt)
+    sh = rdist.FrameSharder(rd, plt, W, H, rank, world, 32, 32, torch.device("cuda", 0))
+    frames = []
+    for f in range(4):                      # progressive: every frame is a different picture
+        rd.TraceRays(plt, 0, 0, 0, W, H)
+        sh.gather_image(dev.rdImage)
+        dev.set_rtprop(totalSamples=f + 1)
+        if rank == 0:
+            frames.append(rd.ReadBuffer(plt, dev.rdImage, W * H * 4).copy())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "sharded.npy"), np.stack(frames))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_gather_every_frame(mods, tmp_path):
+    """two ranks (sharing this box's one GPU, gloo transport: same code path as RCCL up to the transfer) render four
+    DIFFERENT progressive frames, each gathered to rank 0 through FrameSharder's alternating staging buffers: every frame
+    rank 0 sees must equal the unsharded frame of the same sample count"""
+    import torch.multiprocessing as mp
+    rd, scenes = mods
+    port = 29600 + (os.getpid() % 1000)
+    mp.get_context("spawn")
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(str(tmp_path / "sharded.npy"))
+    W, H = 200, 120
+    dev = scenes.DeviceScene(scenes.c1_cornell(W, H, spp=1, depth=3, sphere_subdiv=2))
+    rd.SetShard(0, 1, 64, 64)
+    for f in range(4):
+        rd.TraceRays(dev.plt, 0, 0, 0, W, H)
+        dev.set_rtprop(totalSamples=f + 1)
+        assert np.array_equal(rd.ReadBuffer(dev.plt, dev.rdImage, W * H * 4), got[f]), f
+    assert not np.array_equal(got[0], got[3])
