@@ -14,7 +14,7 @@
 #ifndef __OPENCL_CL_H
 typedef struct rdx_buffer_s* cl_mem;
 typedef struct rdx_shader_s* cl_kernel;
-typedef void* cl_sampler;
+typedef struct rdx_sampler_s* cl_sampler;
 #define CL_ADDRESS_CLAMP_TO_EDGE 0x1131
 #define CL_ADDRESS_CLAMP 0x1132
 #define CL_ADDRESS_REPEAT 0x1133

@@ -145,12 +145,12 @@ inline void FileToTopAccelStruct(Platform*, const char* path, TopAccelStruct* ac
 // ---- resources ----------------------------------------------------------------------------------------
 inline Buffer CreateBuffer(Platform*, unsigned int size) { return detail::need(rdx_buffer_create(size), "CreateBuffer"); }
 inline Image CreateImage(Platform*, unsigned int width, unsigned int height) { return detail::need(rdx_buffer_create((size_t)width * height * CHANNEL), "CreateImage"); }
-// texture arrays / samplers are accepted for source compatibility; the live reference shader never
-// samples them (samples/shader.cl:379,411,421,445), so no device storage backs them yet
-inline ImageArray CreateImageArray(Platform*, unsigned int, unsigned int, unsigned int) { return nullptr; }
-inline Sampler CreateSampler(Platform*, AddressingMode, FilterMode) { return nullptr; }
-inline void ReadImage(Platform*, ImageArray, unsigned int, unsigned int, size_t, void*) {}
-inline void WriteImage(Platform*, ImageArray, unsigned int, unsigned int, size_t, void*) {}
+// texture arrays / samplers (radiance.cpp:96-137, 202-224): RGBA8 2D image arrays; sampled by the stock shader when option
+// "textures" is on (the live reference shader has its reads commented out, see rdx.h)
+inline ImageArray CreateImageArray(Platform*, unsigned int width, unsigned int height, unsigned int arraySize) { return detail::need(rdx_image_array_create(width, height, arraySize), "CreateImageArray"); }
+inline Sampler CreateSampler(Platform*, AddressingMode addressingMode, FilterMode filterMode) { return detail::need(rdx_sampler_create(addressingMode, filterMode), "CreateSampler"); }
+inline void ReadImage(Platform*, ImageArray handle, unsigned int width, unsigned int height, size_t arrayIndex, void* data) { if (rdx_image_read(handle, width, height, arrayIndex, data)) detail::fatal("ReadImage"); }
+inline void WriteImage(Platform*, ImageArray handle, unsigned int width, unsigned int height, size_t arrayIndex, void* data) { if (rdx_image_write(handle, width, height, arrayIndex, data)) detail::fatal("WriteImage"); }
 inline void ReadBuffer(Platform*, Buffer handle, size_t size, void* data, size_t offset = 0) { if (rdx_buffer_read(handle, offset, size, data)) detail::fatal("ReadBuffer"); }
 inline void WriteBuffer(Platform*, Buffer handle, size_t size, void* data, size_t offset = 0) { if (rdx_buffer_write(handle, offset, size, data)) detail::fatal("WriteBuffer"); }
 

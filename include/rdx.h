@@ -31,6 +31,7 @@ extern "C" {
 typedef struct rdx_buffer_s* rdx_buffer;   /* replaces RD::Buffer/Image/TopAccelStruct = cl_mem   (radiance.h:12-19) */
 typedef struct rdx_blas_s*   rdx_blas;     /* replaces RD::BottomAccelStruct                     (radiance.h:52-60) */
 typedef struct rdx_shader_s* rdx_shader;   /* replaces RD::ShaderModule = cl_kernel              (radiance.h:79)    */
+typedef struct rdx_sampler_s* rdx_sampler; /* replaces RD::Sampler = cl_sampler                  (radiance.h:16)    */
 
 /* Host instance record, mirrors RD::Instance (radiance.h:67-74). */
 typedef struct rdx_instance {
@@ -55,6 +56,18 @@ int         rdx_buffer_write(rdx_buffer b, size_t offset, size_t size, const voi
 int         rdx_buffer_read(rdx_buffer b, size_t offset, size_t size, void* dst);
 void*       rdx_buffer_device_ptr(rdx_buffer b);
 size_t      rdx_buffer_size(rdx_buffer b);
+
+/* ---- texture arrays and samplers: replaces CreateImageArray / CreateSampler / ReadImage / WriteImage
+ *      (radiance.h:117-124, radiance.cpp:96-137,202-224).  An image array is `layers` RGBA8 images of width x height
+ *      (CL_RGBA / CL_UNSIGNED_INT8, layer-major, rows tightly packed); it is also a buffer (rdx_buffer_read/write see the raw
+ *      bytes).  write / read move the (width, height) top-left region of one layer, host rows tightly packed, like the
+ *      reference's clEnqueue{Write,Read}Image(origin (0,0,layer), region (width,height,1)).  addressingMode / filterMode take
+ *      the CL_ADDRESS_* / CL_FILTER_* values the reference's RD_ADDRESS_* / RD_FILTER_* macros expand to.  Bound to descriptor
+ *      slots 11 and 12; sampled by the stock closest-hit shader only when option "textures" is 1 (see rdx_set_option). */
+rdx_buffer  rdx_image_array_create(uint32_t width, uint32_t height, uint32_t layers);
+int         rdx_image_write(rdx_buffer imageArray, uint32_t width, uint32_t height, size_t layer, const void* rgba8);
+int         rdx_image_read(rdx_buffer imageArray, uint32_t width, uint32_t height, size_t layer, void* rgba8);
+rdx_sampler rdx_sampler_create(uint32_t addressingMode, uint32_t filterMode);
 
 /* ---- acceleration structures: replaces both RD::BuildAccelStruct overloads,
  *      TopAccelStructToFile and FileToTopAccelStruct
@@ -167,7 +180,10 @@ int         rdx_set_profiling(int on);
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 3 = wave-
  * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
  * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
- * cross-checks), "cull" (pool kernel: -1 (default) = automatic, 1 / 0 = on / off: closest-hit rays skip subtrees the ray enters
+ * cross-checks), "textures" (0 (default) / 1.  The live reference shader has every texture read commented out (`uint4 tex =
+ * 0.0f;//read_imageui(...)`, samples/shader.cl:379,411,421,445), so a material with a texture index renders with texel 0; that
+ * is what 0 reproduces, bit for bit.  1 performs the commented-out read -- coord (uv.x, 1 - uv.y, texIdx), as the reference's
+ * older shader2.cl:255-265 does live -- from the image array in slot 11 through the sampler in slot 12), "cull" (pool kernel: -1 (default) = automatic, 1 / 0 = on / off: closest-hit rays skip subtrees the ray enters
  * beyond the best t found so far, every ray skips leaves whose box it misses -- with a 2^-8 relative margin; results are
  * verified bit-identical to the reference's exhaustive walk, see kernels.hip "culled walk"; automatic = on for scenes with
  * at least 16 k inner BVH nodes), "top_flat" (1 (default) / 0: the pool kernel evaluates a top-level tree of <= 64 nodes all at once per

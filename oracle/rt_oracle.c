@@ -724,6 +724,56 @@ static void getUV(SceneData* sd, HitData* hd, float* u, float* v)
     *v = hd->barycentric.x * v0 + hd->barycentric.y * v1 + hd->barycentric.z * v2;
 }
 
+/* read_imageui(imageArray, sampler, (float4)(u, v, layer, 0)) on a CL_RGBA / CL_UNSIGNED_INT8 2D image array, normalized
+ * coordinates: OpenCL 1.2 specification 8.2 (addressing) and 5.3.3 (layer = clamp(rint(layer), 0, layers-1)).  The spec leaves
+ * CLK_FILTER_LINEAR undefined for integer reads; defined here (and in the product) as the bilinear weights of 8.2 on the 8-bit
+ * values, rounded to nearest.  The live reference shader has these reads commented out: "parity unpinned". */
+static int tex_addr(float s, int n, uint32_t mode, float* u)
+{
+    if (mode == 0) { *u = (s - floorf(s)) * (float)n; int i = (int)floorf(*u); return i > n - 1 ? i - n : i; }
+    if (mode == 3) { float sp = 2.0f * rintf(0.5f * s); sp = fabsf(s - sp); *u = sp * (float)n; int i = (int)floorf(*u); return i > n - 1 ? n - 1 : i; }
+    *u = s * (float)n;
+    int i = (int)floorf(*u);
+    if (mode == 1) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    return (i < 0 || i > n - 1) ? -1 : i;
+}
+static int tex_wrap(int i, int n, uint32_t mode)
+{
+    if (mode == 0) return i < 0 ? i + n : (i > n - 1 ? i - n : i);
+    if (mode == 3 || mode == 1) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    return (i < 0 || i > n - 1) ? -1 : i;
+}
+static void tex_texel(const OrcBindings* b, int layer, int x, int y, float* out)
+{
+    if (x < 0 || y < 0) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    const uint8_t* t = b->texData + (((size_t)layer * b->texH + (uint32_t)y) * b->texW + (uint32_t)x) * 4;
+    out[0] = (float)t[0]; out[1] = (float)t[1]; out[2] = (float)t[2]; out[3] = (float)t[3];
+}
+static void read_imageui(const OrcBindings* b, float u, float v, float layerF, uint32_t* out)
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!(b->texFlags & 1u) || !b->texData) return;          /* live reference shader: tex = 0 */
+    const uint32_t mode = (b->texFlags >> 4) & 3u;
+    int layer = (int)rintf(layerF);
+    layer = layer < 0 ? 0 : (layer > (int)b->texLayers - 1 ? (int)b->texLayers - 1 : layer);
+    float uu, vv, c[4];
+    const int ix = tex_addr(u, (int)b->texW, mode, &uu), iy = tex_addr(v, (int)b->texH, mode, &vv);
+    if (!(b->texFlags & 2u)) {
+        tex_texel(b, layer, ix, iy, c);
+        for (int k = 0; k < 4; ++k) out[k] = (uint32_t)c[k];
+        return;
+    }
+    const float fu = uu - 0.5f, fv = vv - 0.5f;
+    const int i0 = (int)floorf(fu), j0 = (int)floorf(fv);
+    const float a = fu - floorf(fu), bb = fv - floorf(fv);
+    const int x0 = tex_wrap(i0, (int)b->texW, mode), x1 = tex_wrap(i0 + 1, (int)b->texW, mode);
+    const int y0 = tex_wrap(j0, (int)b->texH, mode), y1 = tex_wrap(j0 + 1, (int)b->texH, mode);
+    float t00[4], t10[4], t01[4], t11[4];
+    tex_texel(b, layer, x0, y0, t00); tex_texel(b, layer, x1, y0, t10); tex_texel(b, layer, x0, y1, t01); tex_texel(b, layer, x1, y1, t11);
+    for (int k = 0; k < 4; ++k)
+        out[k] = (uint32_t)((1.0f - a) * (1.0f - bb) * t00[k] + a * (1.0f - bb) * t10[k] + (1.0f - a) * bb * t01[k] + a * bb * t11[k] + 0.5f);
+}
+
 /* shader.cl:340-368 */
 static f3 getFaceNormal(SceneData* sd, HitData* hd)
 {
@@ -743,13 +793,17 @@ static f3 getFaceNormal(SceneData* sd, HitData* hd)
     return cl_normalize3(F3(tmp.x, tmp.y, tmp.z));
 }
 
-/* shader.cl:370-396 ; read_imageui is commented out in the reference => tex == 0 */
+/* shader.cl:370-396 ; read_imageui is commented out in the reference => tex == 0 unless texFlags enables the read */
 static f3 getMatNormal(SceneData* sd, HitData* hd, f3 faceNormal)
 {
     const OrcMeshInfo* meshInfo = &sd->b->meshInfoData[hd->instanceIndex];
     const OrcMaterial* material = &sd->b->materials[meshInfo->materialIndex];
     if (material->normalTexIdx != -1) {
-        float texx = 0, texy = 0, texz = 0;
+        float u, v;
+        uint32_t tex[4];
+        getUV(sd, hd, &u, &v);
+        read_imageui(sd->b, u, 1.0f - v, (float)material->normalTexIdx, tex);
+        float texx = (float)tex[0], texy = (float)tex[1], texz = (float)tex[2];
         f4 localNormal = {cl_clamp(texx / 255.0f, 0.0f, 1.0f), cl_clamp(texy / 255.0f, 0.0f, 1.0f),
                           cl_clamp(texz / 255.0f, 0.0f, 1.0f), 0.0f};
         f4 ln2 = {localNormal.x * 2.0f - 1.0f, localNormal.y * 2.0f - 1.0f, localNormal.z * 2.0f - 1.0f,
@@ -774,13 +828,19 @@ static f4 getMaterialProp(SceneData* sd, HitData* hd)
     float metallicFrag;
     if (material->metallicTexIdx == -1)
         metallicFrag = material->metallic;
-    else
-        metallicFrag = cl_clamp(0 / 255.0f, 0.0f, 1.0f);
+    else {
+        uint32_t tex[4];
+        read_imageui(sd->b, u, 1.0f - v, (float)material->metallicTexIdx, tex);
+        metallicFrag = cl_clamp((float)tex[2] / 255.0f, 0.0f, 1.0f);
+    }
     float roughnessFrag;
     if (material->roughnessTexIdx == -1)
         roughnessFrag = cl_clamp(material->roughness, 0.0f, 1.0f);
-    else
-        roughnessFrag = cl_clamp(0 / 255.0f, 0.05f, 1.0f);
+    else {
+        uint32_t tex[4];
+        read_imageui(sd->b, u, 1.0f - v, (float)material->roughnessTexIdx, tex);
+        roughnessFrag = cl_clamp((float)tex[1] / 255.0f, 0.05f, 1.0f);
+    }
     float transFrag = cl_clamp(material->transmission, 0.0f, 1.0f);
     float iorFrag = cl_clamp(material->ior, 0.0f, 10.0f);
     f4 r = {metallicFrag, roughnessFrag, transFrag, iorFrag};
@@ -794,8 +854,11 @@ static f3 getAlbedo(SceneData* sd, HitData* hd)
     const OrcMaterial* material = &sd->b->materials[meshInfo->materialIndex];
     if (material->albedoTexIdx == -1)
         return F3(material->albedo[0], material->albedo[1], material->albedo[2]);
-    float z = cl_clamp(0 / 255.0f, 0.0f, 1.0f);
-    return F3(z, z, z);
+    float u, v;
+    uint32_t tex[4];
+    getUV(sd, hd, &u, &v);
+    read_imageui(sd->b, u, 1.0f - v, (float)material->albedoTexIdx, tex);
+    return F3(cl_clamp((float)tex[0] / 255.0f, 0.0f, 1.0f), cl_clamp((float)tex[1] / 255.0f, 0.0f, 1.0f), cl_clamp((float)tex[2] / 255.0f, 0.0f, 1.0f));
 }
 
 /* shader.cl:454-469 */

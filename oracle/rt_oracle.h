@@ -116,6 +116,11 @@ typedef struct {
     const float*          normalData;
     const OrcMaterial*    materials;
     const void*           topLevel;     /* TLAS blob */
+    /* slots 11 + 12 (texture array + sampler).  texFlags = 0: texture reads return 0, as in the live reference shader
+     * (`uint4 tex = 0.0f;//read_imageui(...)`, shader.cl:379-445).  Otherwise: bit 0 enabled, bit 1 linear filter,
+     * bits 4-5 addressing (0 repeat, 1 clamp-to-edge, 2 clamp, 3 mirrored repeat) -- the product's TexView flags. */
+    const uint8_t*        texData;      /* RGBA8, layer-major */
+    uint32_t              texW, texH, texLayers, texFlags;
 } OrcBindings;
 
 /* ---- builder */

@@ -68,6 +68,10 @@ SIGNATURES = {
     "rdx_buffer_read": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "rdx_buffer_device_ptr": (C.c_void_p, [C.c_void_p]),
     "rdx_buffer_size": (C.c_size_t, [C.c_void_p]),
+    "rdx_image_array_create": (C.c_void_p, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rdx_image_write": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]),
+    "rdx_image_read": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]),
+    "rdx_sampler_create": (C.c_void_p, [C.c_uint32, C.c_uint32]),
     "rdx_blas_build": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "rdx_blas_build_many": (C.c_int, [C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_void_p)]),

@@ -33,13 +33,21 @@ constexpr uint32_t RDX_COOP_MAX_INSTANCES = 1u << 10;    // key: instance slot <
 constexpr uint32_t RDX_COOP_MAX_BLAS_TRIS = 1u << 22;
 constexpr uint32_t RDX_LDS_WORDS_PER_WAVE_MAX = 16384u;  // 64 KB per workgroup of one wave
 
-struct SceneArgs {                 // descriptor slots 4-10 (samples/shader.cl:175-190)
+// descriptor slots 11 + 12: the RGBA8 texture array and its sampler (radiance.cpp:96-137; read by the commented-out
+// read_imageui calls of samples/shader.cl:379-445, live in shader2.cl:255-265).  flags = 0: the stock pipeline behaves
+// like the LIVE reference shader, whose texture reads are stubbed to 0.
+enum : uint32_t { TEX_ENABLED = 1u, TEX_LINEAR = 2u, TEX_ADDR_SHIFT = 4u,      // flags
+                  TEX_ADDR_REPEAT = 0u, TEX_ADDR_CLAMP_TO_EDGE = 1u, TEX_ADDR_CLAMP = 2u, TEX_ADDR_MIRRORED = 3u };
+struct TexView { const uint8_t* data; uint32_t w, h, layers, flags; };
+
+struct SceneArgs {                 // descriptor slots 4-12 (samples/shader.cl:175-190)
     const SceneProperties* scene;
     const MeshInfo* meshInfo;
     const uint32_t* indexData;
     const float* uvData;
     const float* normalData;
     const Material* materials;
+    TexView tex;
 };
 
 struct CameraArgs {                // slot 3 + per-frame constants hoisted out of generateRay

@@ -530,7 +530,7 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
         p.nextFactor = mk3(1.f, 1.f, 1.f);
         p.nextRayOrigin = mk3(ro.x, ro.y, ro.z); p.nextRayDirection = mk3(rd.x, rd.y, rd.z);
         p.shadowOrigin = p.nextRayOrigin;
-        const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials};
+        const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials, sc.tex};
         if (instSlot != RDX_MISS) {
             const float4 ha = ps.hitA[i];
             HitInfo h;
@@ -973,7 +973,7 @@ struct PathPolicy {
         p.color = mk3(0.f, 0.f, 0.f); p.colorOccluded = p.color;
         p.nextFactor = mk3(1.f, 1.f, 1.f);
         p.nextRayOrigin = o; p.nextRayDirection = d; p.shadowOrigin = o;
-        const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials};
+        const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials, sc.tex};
         HitInfo h;
         fill_hit_info(A, st.inst, o, d, st.t, st.b1, st.b2, A.tris[st.triSlot].primID, h);
         callHit((int)A.insts[st.inst].SBTOffset + 1, p, h, sv, d, st.frameID, st.pixel, st.depth, st.depth + 1 < maxDepth);
@@ -1090,7 +1090,7 @@ k_material_batch(SceneArgs sc, const rdx_hit* __restrict__ hits, const float* __
     h.bx = hh.barycentric[0]; h.by = hh.barycentric[1]; h.bz = hh.barycentric[2];
     h.primitiveIndex = hh.primitiveIndex; h.instanceIndex = hh.instanceIndex;
     h.fwd = hh.transform;
-    const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials};
+    const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials, sc.tex};
     Payload p;
     p.hit = false; p.wantsShadowRay = false;
     p.color = p.colorOccluded = p.nextFactor = p.nextRayOrigin = p.nextRayDirection = p.shadowOrigin = mk3(0.f, 0.f, 0.f);

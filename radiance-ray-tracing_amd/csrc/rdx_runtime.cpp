@@ -69,7 +69,9 @@ struct rdx_buffer_s {
     // written through the API since creation (device code never writes them); wrapped memory is never mirrored.
     std::vector<uint8_t> mirror;
     bool mirrorValid = false;
+    uint32_t imgW = 0, imgH = 0, imgLayers = 0;   // != 0: an RGBA8 image array created by rdx_image_array_create
 };
+struct rdx_sampler_s { uint32_t addressing = 0, filter = 0; };
 struct rdx_blas_s { std::unique_ptr<Blas> blas; };
 struct rdx_shader_s { std::string name; bool hasRaygen = false; };
 
@@ -119,6 +121,8 @@ struct Context {
     bool countVisits = false, profiling = false;
     int inlineLeafRoots = 1;                // pool engine: single-leaf BLASes handled in the flat top-level step (option "inline_leaf_roots")
     int cull = -1;                          // pool engine: culled walk (option "cull"): 1 on, 0 off, -1 = on for scenes of >= 16 k inner nodes
+    int textures = 0;                       // option "textures": 1 = the stock shader samples the bound image array
+    std::vector<std::unique_ptr<rdx_sampler_s>> samplers;
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
@@ -539,6 +543,22 @@ int scene_args(SceneArgs& sc)
     sc.normalData = static_cast<const float*>(ptr(9));
     sc.materials = static_cast<const Material*>(ptr(10));
     if (static_cast<rdx_buffer_s*>(g.slots[4])->size < sizeof(SceneProperties)) return fail("scene buffer smaller than SceneProperties");
+    // slots 11 / 12: texture array + sampler.  Read only when option "textures" is on (the live reference shader has its
+    // reads stubbed to 0, samples/shader.cl:379-445)
+    sc.tex = TexView{nullptr, 0, 0, 0, 0};
+    if (g.textures && g.slots[11] && known_buffer(g.slots[11])) {
+        const auto* img = static_cast<const rdx_buffer_s*>(g.slots[11]);
+        if (img->imgW && img->imgH && img->imgLayers) {
+            uint32_t mode = TEX_ADDR_REPEAT, linear = 0;           // no sampler bound: repeat + nearest
+            for (auto& sm : g.samplers)
+                if (sm.get() == g.slots[12]) {
+                    mode = sm->addressing == 0x1131 ? TEX_ADDR_CLAMP_TO_EDGE : sm->addressing == 0x1132 ? TEX_ADDR_CLAMP
+                         : sm->addressing == 0x1134 ? TEX_ADDR_MIRRORED : TEX_ADDR_REPEAT;
+                    linear = sm->filter == 0x1141 ? TEX_LINEAR : 0u;
+                }
+            sc.tex = TexView{static_cast<const uint8_t*>(img->dptr), img->imgW, img->imgH, img->imgLayers, TEX_ENABLED | linear | (mode << TEX_ADDR_SHIFT)};
+        }
+    }
     return 0;
 }
 
@@ -661,6 +681,57 @@ extern "C" rdx_buffer rdx_buffer_create(size_t size)
     HIP_OKP(hipMemset(b->dptr, 0, std::max<size_t>(size, 16)));
     g.buffers.push_back(std::move(b));
     return g.buffers.back().get();
+}
+
+// ---- texture arrays and samplers: replaces CreateImageArray / CreateSampler / ReadImage / WriteImage
+//      (radiance/src/radiance.cpp:96-137, 202-224): a 2D image array of CL_RGBA / CL_UNSIGNED_INT8 texels, layer-major
+extern "C" rdx_buffer rdx_image_array_create(uint32_t width, uint32_t height, uint32_t layers)
+{
+    if ((uint64_t)width * height * std::max(layers, 1u) * 4ull > (1ull << 36)) { fail("CreateImageArray: %ux%ux%u is too large", width, height, layers); return nullptr; }
+    rdx_buffer b = rdx_buffer_create((size_t)width * height * layers * 4);
+    if (!b) return nullptr;
+    b->imgW = width; b->imgH = height; b->imgLayers = layers;
+    return b;
+}
+
+static int image_region(rdx_buffer img, uint32_t width, uint32_t height, size_t layer, const char* what)
+{
+    if (!img || !known_buffer(img) || !img->imgW) return fail("%s: not an image array", what);
+    if (layer >= img->imgLayers) return fail("%s: layer %zu of %u", what, layer, img->imgLayers);
+    if (width > img->imgW || height > img->imgH) return fail("%s: region %ux%u exceeds the image (%ux%u)", what, width, height, img->imgW, img->imgH);
+    return 0;
+}
+
+// origin (0, 0, layer), region (width, height, 1), host rows tightly packed -- as radiance.cpp:202-224 calls clEnqueue{Write,Read}Image
+extern "C" int rdx_image_write(rdx_buffer img, uint32_t width, uint32_t height, size_t layer, const void* rgba8)
+{
+    if (image_region(img, width, height, layer, "WriteImage")) return -1;
+    if (!width || !height) return 0;
+    uint8_t* dst = static_cast<uint8_t*>(img->dptr) + layer * (size_t)img->imgW * img->imgH * 4;
+    HIP_OK(hipMemcpy2D(dst, (size_t)img->imgW * 4, rgba8, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyHostToDevice));
+    ++img->version;
+    return 0;
+}
+
+extern "C" int rdx_image_read(rdx_buffer img, uint32_t width, uint32_t height, size_t layer, void* rgba8)
+{
+    if (image_region(img, width, height, layer, "ReadImage")) return -1;
+    if (!width || !height) return 0;
+    const uint8_t* src = static_cast<const uint8_t*>(img->dptr) + layer * (size_t)img->imgW * img->imgH * 4;
+    HIP_OK(hipMemcpy2D(rgba8, (size_t)width * 4, src, (size_t)img->imgW * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" rdx_sampler rdx_sampler_create(uint32_t addressingMode, uint32_t filterMode)
+{
+    if (addressingMode < 0x1131 || addressingMode > 0x1134 || (filterMode != 0x1140 && filterMode != 0x1141)) {
+        fail("CreateSampler: addressing mode 0x%x / filter mode 0x%x are not CL_ADDRESS_* / CL_FILTER_* values", addressingMode, filterMode);
+        return nullptr;
+    }
+    auto sm = std::make_unique<rdx_sampler_s>();
+    sm->addressing = addressingMode; sm->filter = filterMode;
+    g.samplers.push_back(std::move(sm));
+    return g.samplers.back().get();
 }
 
 extern "C" rdx_buffer rdx_buffer_wrap(void* device_ptr, size_t size)
@@ -1007,6 +1078,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "overlap")) { if (value < 0 || value > 1) return fail("overlap must be 0 or 1"); g.overlap = (int)value; return 0; }
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
+    if (!strcmp(name, "textures")) { g.textures = value != 0; return 0; }
     if (!strcmp(name, "cull")) { g.cull = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }

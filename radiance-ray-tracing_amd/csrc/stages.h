@@ -8,6 +8,7 @@
 // and the any-hit traversal stage picks one afterwards.  Arithmetic per value is unchanged.
 #pragma once
 #include "device_math.h"
+#include "kernels.h"
 #include "rdx_types.h"
 #include "sbt_generated.h"
 
@@ -22,6 +23,7 @@ struct SceneView {                  // descriptor slots 4-10 of the raygen kerne
     const float* uvData;
     const float* normalData;
     const Material* materials;
+    TexView tex;                    // slots 11 + 12 (disabled unless option "textures" is on and an image array is bound)
 };
 
 struct HitInfo {                    // what struct HitData (radiance.cl:8-18) carries into a hit shader
@@ -220,6 +222,57 @@ __device__ inline f3 offset_hit_position(const HitInfo& h, f3 n)
     return p + n * 0.00001f;
 }
 
+// ---- texture array reads -------------------------------------------------------------------------------------------
+// read_imageui(imageArray, sampler, (float4)(u, v, layer, 0)) on a CL_RGBA / CL_UNSIGNED_INT8 2D image array with a
+// normalized-coordinate sampler, per the OpenCL 1.2 specification, section 8.2 (addressing modes) and 5.3.3 (array layer =
+// clamp(rint(layer), 0, layers - 1)).  The specification leaves CLK_FILTER_LINEAR undefined for integer reads; the
+// reference binds a linear sampler (tools/sceneBuilder.cpp:40), so linear is DEFINED here as the spec's bilinear weights on
+// the 8-bit values, rounded to nearest.  The live reference shader never reaches this code ("parity unpinned").
+__device__ inline int tex_addr(float s, int n, uint32_t mode, float& u)          // -> nearest texel index (or -1: border), u = unnormalised
+{
+    if (mode == TEX_ADDR_REPEAT) { u = (s - floorf(s)) * (float)n; int i = (int)floorf(u); return i > n - 1 ? i - n : i; }
+    if (mode == TEX_ADDR_MIRRORED) { float sp = 2.0f * rintf(0.5f * s); sp = fabsf(s - sp); u = sp * (float)n; int i = (int)floorf(u); return i > n - 1 ? n - 1 : i; }
+    u = s * (float)n;
+    const int i = (int)floorf(u);
+    if (mode == TEX_ADDR_CLAMP_TO_EDGE) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    return (i < 0 || i > n - 1) ? -1 : i;                                          // CLAMP: border colour (0, 0, 0, 0)
+}
+__device__ inline int tex_wrap(int i, int n, uint32_t mode)                       // neighbour index of the linear filter
+{
+    if (mode == TEX_ADDR_REPEAT) return i < 0 ? i + n : (i > n - 1 ? i - n : i);
+    if (mode == TEX_ADDR_MIRRORED || mode == TEX_ADDR_CLAMP_TO_EDGE) return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    return (i < 0 || i > n - 1) ? -1 : i;
+}
+__device__ inline void tex_texel(const TexView& T, int layer, int x, int y, float out[4])
+{
+    if (x < 0 || y < 0) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    const uchar4 t = reinterpret_cast<const uchar4*>(T.data)[((size_t)layer * T.h + (uint32_t)y) * T.w + (uint32_t)x];
+    out[0] = (float)t.x; out[1] = (float)t.y; out[2] = (float)t.z; out[3] = (float)t.w;
+}
+__device__ inline void tex_read_ui(const TexView& T, float u, float v, float layerF, uint32_t out[4])
+{
+    const uint32_t mode = (T.flags >> TEX_ADDR_SHIFT) & 3u;
+    int layer = (int)rintf(layerF);
+    layer = layer < 0 ? 0 : (layer > (int)T.layers - 1 ? (int)T.layers - 1 : layer);
+    float uu, vv;
+    const int ix = tex_addr(u, (int)T.w, mode, uu), iy = tex_addr(v, (int)T.h, mode, vv);
+    float c[4];
+    if (!(T.flags & TEX_LINEAR)) {
+        tex_texel(T, layer, ix, iy, c);
+        for (int k = 0; k < 4; ++k) out[k] = (uint32_t)c[k];
+        return;
+    }
+    const float fu = uu - 0.5f, fv = vv - 0.5f;
+    const int i0 = (int)floorf(fu), j0 = (int)floorf(fv);
+    const float a = fu - floorf(fu), b = fv - floorf(fv);
+    const int x0 = tex_wrap(i0, (int)T.w, mode), x1 = tex_wrap(i0 + 1, (int)T.w, mode);
+    const int y0 = tex_wrap(j0, (int)T.h, mode), y1 = tex_wrap(j0 + 1, (int)T.h, mode);
+    float t00[4], t10[4], t01[4], t11[4];
+    tex_texel(T, layer, x0, y0, t00); tex_texel(T, layer, x1, y0, t10); tex_texel(T, layer, x0, y1, t01); tex_texel(T, layer, x1, y1, t11);
+    for (int k = 0; k < 4; ++k)
+        out[k] = (uint32_t)((1.0f - a) * (1.0f - b) * t00[k] + a * (1.0f - b) * t10[k] + (1.0f - a) * b * t01[k] + a * b * t11[k] + 0.5f);
+}
+
 // closest-hit, SBT row 1 (shader.cl:482-541).  `sampleNext` = false on the last bounce, whose
 // sampled direction the raygen loop never uses.
 __device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s, f3 rayDir, uint32_t frameID,
@@ -246,10 +299,22 @@ __device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s
     f3 faceN = normalize3(mat4_mul3(h.fwd, nl.x, nl.y, nl.z, nw));
     f3 hitPos = offset_hit_position(h, faceN);
 
-    // texture fetches are stubbed to 0 in the live reference shader (shader.cl:379,411,421,445)
+    // Texture fetches are stubbed to 0 in the live reference shader (`uint4 tex = 0.0f;//read_imageui(...)`,
+    // shader.cl:379,411,421,445): that is what runs unless option "textures" is on and an image array is bound, in which case
+    // the commented-out read happens: coord = (uv.x, 1 - uv.y, texIdx) (shader.cl:378,410,420,444; live in shader2.cl:255-265).
+    const bool texOn = (s.tex.flags & TEX_ENABLED) != 0u;
+    float tu = 0.0f, tv = 0.0f;
+    if (texOn) {     // getUV, shader.cl:323-338
+        const float* ub = s.uvData + mi.uvOffset;
+        tu = h.bx * ub[i0 * 3] + h.by * ub[i1 * 3] + h.bz * ub[i2 * 3];
+        tv = h.bx * ub[i0 * 3 + 1] + h.by * ub[i1 * 3 + 1] + h.bz * ub[i2 * 3 + 1];
+    }
     f3 N = faceN;
     if (mt.normalTexIdx != -1) {
-        f4 t; t.x = cl_clamp(0.0f / 255.0f, 0.0f, 1.0f) * 2.0f - 1.0f; t.y = t.x; t.z = t.x; t.w = 0.0f * 2.0f - 1.0f;
+        uint32_t tx[4] = {0u, 0u, 0u, 0u};
+        if (texOn) tex_read_ui(s.tex, tu, 1.0f - tv, (float)mt.normalTexIdx, tx);
+        f4 t; t.x = cl_clamp((float)tx[0] / 255.0f, 0.0f, 1.0f) * 2.0f - 1.0f; t.y = cl_clamp((float)tx[1] / 255.0f, 0.0f, 1.0f) * 2.0f - 1.0f;
+        t.z = cl_clamp((float)tx[2] / 255.0f, 0.0f, 1.0f) * 2.0f - 1.0f; t.w = 0.0f * 2.0f - 1.0f;
         t = normalize4(t);
         float tbn[16];
         normal_space(faceN, tbn);
@@ -259,12 +324,26 @@ __device__ inline void material(Payload& p, const HitInfo& h, const SceneView& s
     f3 L = normalize3(mk3(-ld[0], -ld[1], -ld[2]));
     f3 V = normalize3(-rayDir);
 
-    float metallic = (mt.metallicTexIdx == -1) ? mt.metallic : cl_clamp(0.0f / 255.0f, 0.0f, 1.0f);
-    float roughness = (mt.roughnessTexIdx == -1) ? cl_clamp(mt.roughness, 0.0f, 1.0f) : cl_clamp(0.0f / 255.0f, 0.05f, 1.0f);
+    float metallic = mt.metallic;
+    if (mt.metallicTexIdx != -1) {
+        uint32_t tx[4] = {0u, 0u, 0u, 0u};
+        if (texOn) tex_read_ui(s.tex, tu, 1.0f - tv, (float)mt.metallicTexIdx, tx);
+        metallic = cl_clamp((float)tx[2] / 255.0f, 0.0f, 1.0f);                   // .z (shader.cl:412)
+    }
+    float roughness = cl_clamp(mt.roughness, 0.0f, 1.0f);
+    if (mt.roughnessTexIdx != -1) {
+        uint32_t tx[4] = {0u, 0u, 0u, 0u};
+        if (texOn) tex_read_ui(s.tex, tu, 1.0f - tv, (float)mt.roughnessTexIdx, tx);
+        roughness = cl_clamp((float)tx[1] / 255.0f, 0.05f, 1.0f);                 // .y (shader.cl:422)
+    }
     float transmission = cl_clamp(mt.transmission, 0.0f, 1.0f);
     float ior = cl_clamp(mt.ior, 0.0f, 10.0f);
-    f3 albedo = (mt.albedoTexIdx == -1) ? mk3(mt.albedo[0], mt.albedo[1], mt.albedo[2])
-                                        : mk3(cl_clamp(0.0f / 255.0f, 0.0f, 1.0f), cl_clamp(0.0f / 255.0f, 0.0f, 1.0f), cl_clamp(0.0f / 255.0f, 0.0f, 1.0f));
+    f3 albedo = mk3(mt.albedo[0], mt.albedo[1], mt.albedo[2]);
+    if (mt.albedoTexIdx != -1) {
+        uint32_t tx[4] = {0u, 0u, 0u, 0u};
+        if (texOn) tex_read_ui(s.tex, tu, 1.0f - tv, (float)mt.albedoTexIdx, tx);
+        albedo = mk3(cl_clamp((float)tx[0] / 255.0f, 0.0f, 1.0f), cl_clamp((float)tx[1] / 255.0f, 0.0f, 1.0f), cl_clamp((float)tx[2] / 255.0f, 0.0f, 1.0f));
+    }
 
     // deferred shadow query: traceRay(topLevel, 2, 4, hitPos, L, 0.001, 1000) (shader.cl:499-501)
     p.wantsShadowRay = true;

@@ -236,14 +236,36 @@ def CreateImage(platform, width, height):
     return CreateBuffer(platform, int(width) * int(height) * CHANNEL)
 
 
+class Sampler:
+    def __init__(self, handle, addressingMode, filterMode):
+        self.handle, self.addressingMode, self.filterMode = handle, addressingMode, filterMode
+
+
 def CreateImageArray(platform, width, height, arraySize):
-    """Texture arrays are accepted for source compatibility; the live reference shader never samples
-    them (samples/shader.cl:379,411,421,445), so no device storage is created."""
-    return None
+    """radiance.cpp:96-120: `arraySize` RGBA8 images of width x height (CL_RGBA / CL_UNSIGNED_INT8)"""
+    h = _handle(_lib.lib().rdx_image_array_create(int(width), int(height), int(arraySize)), "CreateImageArray")
+    b = Buffer(h, int(width) * int(height) * int(arraySize) * 4)
+    b.width, b.height, b.arraySize = int(width), int(height), int(arraySize)
+    return b
 
 
 def CreateSampler(platform, addressingMode, filterMode):
-    return None
+    """radiance.cpp:122-130 (normalized coordinates)"""
+    return Sampler(_handle(_lib.lib().rdx_sampler_create(int(addressingMode), int(filterMode)), "CreateSampler"), addressingMode, filterMode)
+
+
+def WriteImage(platform, handle, width, height, arrayIndex, data):
+    """radiance.cpp:214-224: the (width, height) region at the origin of layer `arrayIndex`, RGBA8, rows tightly packed"""
+    keep, ptr = _as_bytes_ptr(data, int(width) * int(height) * 4)
+    _check(_lib.lib().rdx_image_write(handle.handle, int(width), int(height), int(arrayIndex), ptr))
+
+
+def ReadImage(platform, handle, width, height, arrayIndex, data=None):
+    """radiance.cpp:202-212"""
+    if data is None:
+        data = np.empty((int(height), int(width), 4), np.uint8)
+    _check(_lib.lib().rdx_image_read(handle.handle, int(width), int(height), int(arrayIndex), data.ctypes.data))
+    return data
 
 
 def WrapDeviceMemory(platform, device_ptr, size, keepalive=None):
@@ -299,7 +321,7 @@ def BindDescriptorSet(platform, descriptorSet):
     n = len(descriptorSet)
     arr = (C.c_void_p * max(n, 1))()
     for i, h in enumerate(descriptorSet):
-        arr[i] = h.handle if isinstance(h, Buffer) else None
+        arr[i] = h.handle if isinstance(h, (Buffer, Sampler)) else None
     _check(_lib.lib().rdx_bind_descriptor_set(arr, n))
 
 

@@ -38,7 +38,8 @@ class OrcBindings(C.Structure):
     _fields_ = [("RTProp", C.c_void_p), ("imageScratch", C.c_void_p), ("image", C.c_void_p), ("camData", C.c_void_p),
                 ("scene", C.c_void_p), ("meshInfoData", C.c_void_p), ("vertexData", C.c_void_p),
                 ("indexData", C.c_void_p), ("uvData", C.c_void_p), ("normalData", C.c_void_p),
-                ("materials", C.c_void_p), ("topLevel", C.c_void_p)]
+                ("materials", C.c_void_p), ("topLevel", C.c_void_p),
+                ("texData", C.c_void_p), ("texW", C.c_uint32), ("texH", C.c_uint32), ("texLayers", C.c_uint32), ("texFlags", C.c_uint32)]
 
 
 HIT_DTYPE = np.dtype([("hitPoint", "<f4", 3), ("distance", "<f4"), ("primitiveIndex", "<u4"), ("instanceIndex", "<u4"),
@@ -197,7 +198,14 @@ class OracleScene:
                                 self.arrays["meshInfo"].ctypes.data, self.arrays["vertex"].ctypes.data,
                                 self.arrays["index"].ctypes.data, self.arrays["uv"].ctypes.data,
                                 self.arrays["normal"].ctypes.data, self.arrays["material"].ctypes.data,
-                                self.tlas.ctypes.data)
+                                self.tlas.ctypes.data, None, 0, 0, 0, 0)
+
+    def bind_textures(self, texels, addressing=0, linear=False):
+        """texels: (layers, H, W, 4) uint8; addressing 0 repeat, 1 clamp-to-edge, 2 clamp, 3 mirrored repeat"""
+        self.tex = np.ascontiguousarray(texels, np.uint8)
+        self.bind.texData = self.tex.ctypes.data
+        self.bind.texLayers, self.bind.texH, self.bind.texW = self.tex.shape[:3]
+        self.bind.texFlags = 1 | (2 if linear else 0) | (addressing << 4)
 
     def set_rtprop(self, **kw):
         for k, v in kw.items():

@@ -683,3 +683,101 @@ def test_two_ranks_gather_every_frame(mods, tmp_path):
         dev.set_rtprop(totalSamples=f + 1)
         assert np.array_equal(rd.ReadBuffer(dev.plt, dev.rdImage, W * H * 4), got[f]), f
     assert not np.array_equal(got[0], got[3])
+
+
+def _textured_scene(scenes, w, h):
+    """two textured quads + a textured box under the sample1 light: albedo / roughness / metallic / normal texture indices"""
+    s = scenes.Scene("textured")
+    floor = s.add_mesh(scenes.quad([-3, 0, -3], [3, 0, -3], [3, 0, 3], [-3, 0, 3], [0, 1, 0]))
+    wall = s.add_mesh(scenes.quad([-3, 0, 3], [3, 0, 3], [3, 4, 3], [-3, 4, 3], [0, 0, -1]))
+    cube = s.add_mesh(scenes.box([-0.8, 0.0, -0.8], [0.8, 1.6, 0.8]))
+    m0 = scenes.material((0.7, 0.7, 0.7), 0.0, 0.6); m0["albedoTexIdx"] = 0
+    m1 = scenes.material((0.7, 0.7, 0.7), 0.0, 0.6); m1["albedoTexIdx"] = 1; m1["roughnessTexIdx"] = 2; m1["metallicTexIdx"] = 2
+    m2 = scenes.material((0.9, 0.8, 0.5), 0.2, 0.4); m2["albedoTexIdx"] = 0; m2["normalTexIdx"] = 1
+    s.materials = [m0, m1, m2]
+    s.add_instance(floor, None, 0); s.add_instance(wall, None, 1); s.add_instance(cube, scenes.translate(0.3, 0.0, 0.2) @ scenes.rotate_y(25.0), 2)
+    s.camera = scenes.blender_camera(w, h, 0.05, 0.036, 8.0, 0.0, (0.5, 9.0, 2.5), (-100.0, 180.0, 0.0))
+    s.sceneProps = scenes.blender_dir_light(-45.0, 20.0, 6.0)
+    s.rtprop = scenes._rtprop(0, 2, 3)
+    return s
+
+
+def _test_textures(size=64):
+    yy, xx = np.mgrid[0:size, 0:size]
+    t = np.zeros((3, size, size, 4), np.uint8)
+    t[0, ..., 0] = np.where(((xx // 8) + (yy // 8)) % 2, 230, 40); t[0, ..., 1] = 120; t[0, ..., 2] = (xx * 4) % 256; t[0, ..., 3] = 255
+    t[1, ..., 0] = (xx * 3 + yy) % 256; t[1, ..., 1] = (yy * 5) % 256; t[1, ..., 2] = 200; t[1, ..., 3] = 255
+    t[2, ..., 0] = 17; t[2, ..., 1] = 60 + (xx % 16) * 8; t[2, ..., 2] = np.where(yy % 32 < 16, 0, 255); t[2, ..., 3] = 255
+    return t
+
+
+def test_image_array_and_texture_path(mods):
+    """SURVEY 8(f) rank 3.  (1) CreateImageArray / WriteImage / ReadImage (radiance.cpp:96-137,202-224): region writes at the
+    origin of a layer, round trip, errors.  (2) option "textures" 0 (default) reproduces the LIVE reference shader, whose
+    texture reads are commented out -> texel 0: frames of a scene with textured materials equal the oracle's stubbed path.
+    (3) "textures" 1 performs the read (coord (u, 1-v, texIdx), shader2.cl:255-265) for every addressing / filter mode:
+    `material` payloads and frames agree with the oracle's OpenCL-1.2-spec sampler"""
+    rd, scenes = mods
+    plt = rd.Platform.GetPlatform()
+    ia = rd.CreateImageArray(plt, 16, 8, 3)
+    a = np.arange(16 * 8 * 4, dtype=np.uint8).reshape(8, 16, 4)
+    rd.WriteImage(plt, ia, 16, 8, 1, a)
+    assert np.array_equal(rd.ReadImage(plt, ia, 16, 8, 1), a)
+    assert not rd.ReadImage(plt, ia, 16, 8, 0).any() and not rd.ReadImage(plt, ia, 16, 8, 2).any()
+    sub = (np.arange(5 * 3 * 4, dtype=np.uint8) + 100).reshape(3, 5, 4)
+    rd.WriteImage(plt, ia, 5, 3, 2, sub)                                 # a region smaller than the image, at its origin
+    full = rd.ReadImage(plt, ia, 16, 8, 2)
+    assert np.array_equal(full[:3, :5], sub) and not full[3:].any() and not full[:, 5:].any()
+    raw = rd.ReadBuffer(plt, ia, 16 * 8 * 4 * 3).reshape(3, 8, 16, 4)    # layer-major, rows tightly packed
+    assert np.array_equal(raw[1], a)
+    with pytest.raises(rd.RadianceError):
+        rd.WriteImage(plt, ia, 16, 8, 3, a)                              # layer out of range
+    with pytest.raises(rd.RadianceError):
+        rd.ReadImage(plt, ia, 17, 8, 0)
+    with pytest.raises(rd.RadianceError):
+        rd.CreateSampler(plt, 7, rd.RD_FILTER_LINEAR)
+
+    W, H = 96, 54
+    s = _textured_scene(scenes, W, H)
+    tex = _test_textures()
+    dev = scenes.DeviceScene(s)
+    img = rd.CreateImageArray(plt, 64, 64, 3)
+    for l in range(3):
+        rd.WriteImage(plt, img, 64, 64, l, tex[l])
+    osc = ob.OracleScene(s)
+    px = np.arange(W * H, dtype=np.uint32)
+    o, d = rd.GenerateBatch(px, np.stack([np.zeros_like(px), np.zeros_like(px), px], 1))
+    hits = rd.TraceBatch(dev.topAccelStruct, o, d)
+    k = hits["hit"] == 1
+    assert set(np.unique(hits["instanceCustomIndex"][k])) == {0, 1, 2}
+    frames = (px % 5).astype(np.uint32); depths = (px % 3).astype(np.int32)
+    modes = [(rd.RD_ADDRESS_REPEAT, rd.RD_FILTER_LINEAR, 0, True), (rd.RD_ADDRESS_REPEAT, rd.RD_FILTER_NEAREST, 0, False),
+             (rd.RD_ADDRESS_CLAMP_TO_EDGE, rd.RD_FILTER_LINEAR, 1, True), (rd.RD_ADDRESS_CLAMP, rd.RD_FILTER_NEAREST, 2, False),
+             (rd.RD_ADDRESS_MIRRORED_REPEAT, rd.RD_FILTER_LINEAR, 3, True)]
+    try:
+        # (2) default: texel 0, whatever is bound
+        ds = list(dev.descSet); ds[11] = img; ds[12] = rd.CreateSampler(plt, rd.RD_ADDRESS_REPEAT, rd.RD_FILTER_LINEAR)
+        rd.BindDescriptorSet(plt, ds)
+        dev.render(); osc.frame()
+        stub = dev.read_scratch().copy()
+        assert _near_oracle(stub, osc.scratch)
+        # (3) sampled
+        rd.SetOption("textures", 1)
+        outs = []
+        for addr, filt, omode, olin in modes:
+            ds[12] = rd.CreateSampler(plt, addr, filt)
+            rd.BindDescriptorSet(plt, ds)
+            osc.bind_textures(tex, omode, olin)
+            got = rd.MaterialBatch(hits, d, px, frames, depths)
+            ref = osc.material_batch(hits, d, px, frames, depths)
+            for f in ("nextFactor", "nextRayOrigin", "nextRayDirection"):
+                scale = np.maximum(1.0, np.abs(ref[f][k]))
+                assert (np.abs(ref[f][k] - got[f][k]) / scale).max() < 2e-5, (addr, filt, f)
+            dev.set_rtprop(totalSamples=0); dev.clear_scratch(); osc.set_rtprop(totalSamples=0); osc.scratch[:] = 0
+            dev.render(); osc.frame()
+            outs.append(dev.read_scratch().copy())
+            # (a uv within an ulp of a texel boundary picks the neighbouring texel on one side: a few pixels differ visibly)
+            assert _near_oracle(outs[-1], osc.scratch, 0.985, 1e-2), (addr, filt)
+        assert not np.array_equal(outs[0], stub) and not np.array_equal(outs[0], outs[1])      # the textures are really read
+    finally:
+        rd.SetOption("textures", 0)

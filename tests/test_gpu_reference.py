@@ -258,3 +258,15 @@ def test_random_scenes_identical_to_reference(mods, ref):
                 _same_hits(r, g, closest=(rec == 1), tag="seed %d kernel %d cull %d rec %d" % (seed, kernel, cull, rec))
         total += int((r["hit"] == 1).sum())
     assert total > 2000
+
+
+def test_textured_materials_render_like_the_live_reference(mods, ref):
+    """materials WITH texture indices, default options: the live reference shader reads texel 0 for them (its read_imageui
+    calls are commented out, shader.cl:379-445) and so does the product -- frames bit-identical to the reference kernel"""
+    from test_gpu_parity import _textured_scene
+    rd, scenes = mods
+    s = _textured_scene(scenes, 160, 90)
+    dev = scenes.DeviceScene(s)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    rs = rg.RefScene(ref, s, blob)
+    _frames_identical(rd, dev, rs, frames=2)
