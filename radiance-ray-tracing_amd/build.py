@@ -34,10 +34,17 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    # regenerate the SBT tables from samples/sbt.json
+    # regenerate the SBT tables from samples/sbt.json -- or, for a library with another shader binding table
+    # (RDX_SBT_JSON=<file> RDX_LIB_NAME=<name>.so), into a header next to that library, selected with -DRDX_SBT_HEADER
     gen = os.path.join(HERE, "..", "tools", "genSBT.py")
-    subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
-    cmd = [HIPCC] + FLAGS + EXTRA + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    sbt = []
+    if os.environ.get("RDX_SBT_JSON"):
+        hdr = LIB[:-3] + "_sbt.h"
+        subprocess.check_call([sys.executable, gen, os.environ["RDX_SBT_JSON"], hdr], stdout=subprocess.DEVNULL)
+        sbt = ['-DRDX_SBT_HEADER="%s"' % hdr]
+    else:
+        subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
+    cmd = [HIPCC] + FLAGS + EXTRA + sbt + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -39,6 +39,7 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     uint32_t coopNeed = 1;             // wave-cooperative kernel (leaf children are never pushed, smaller subtree first)
     uint32_t topNeed = 1, blasNeed = 0; // its two parts: top-level entries of one ray / entries inside one BLAS (pool engine)
     bool leafRoots = false;             // some instance's BLAS is a single leaf of <= 8 triangles
+    bool sbtOffsets = false;               // an instance has SBTOffset != 0: reference-order kernel only
     uint32_t nWide = 0;                    // inner BLAS nodes of the scene (sizes the automatic choice of the culled walk)
     uint32_t blasNeedAny = 0;              // BLAS stack need of the pool engine when the push order depends on the ray (culled walk)
     uint32_t topFlat = 0, topFlatNeed = 1; // pool engine: number of top-level nodes if they are few enough (<= 64) to be evaluated
@@ -217,13 +218,17 @@ int derive_accel(rdx_buffer_s* tb)
     std::vector<DInst> dI(nInst);
     struct BlasInfo { uint32_t nodeBase; uint32_t need; uint32_t coopNeed; uint32_t anyNeed; uint32_t triBase; uint32_t rootDesc0, rootDesc1; float rootMin[3], rootMax[3]; };
     bool coopOK = nInst <= RDX_COOP_MAX_INSTANCES;
+    bool sbtOffsets = false;
     uint32_t maxLeafChunks = 0;             // extra stack entries an oversized (> 8 triangle) leaf can push
     uint32_t maxLeafTris = 0;
     std::map<uint32_t, BlasInfo> blasAt;    // byte offset -> merged-array base
     for (uint32_t k = 0; k < nInst; ++k) {
         const BlobInst& bi = binst[k];
-        if (bi.SBTOffset != 0)
-            return fail("instance %u has SBTOffset %u: only offset 0 (stock sbt.json rows) is supported", k, bi.SBTOffset);
+        // Dispatch index = instanceSBTOffset + sbtRecordOffset (radiance.cl:281, shader.cl:574-605).  With a non-zero offset the
+        // any-hit shader of a RADIANCE ray's row may end the walk at the first accepted candidate in the reference's DFS order --
+        // an order only the reference-order kernel keeps -- so such scenes are traced by that kernel (the live loader always
+        // writes 0, tools/sceneBuilder.cpp:302; the production engines assume it).
+        if (bi.SBTOffset != 0) sbtOffsets = true;
         auto it = blasAt.find(bi.instanceOffset);
         if (it == blasAt.end()) {
             if ((size_t)bi.instanceOffset + 16 > bsz) return fail("TLAS blob: BLAS offset out of range");
@@ -399,6 +404,7 @@ int derive_accel(rdx_buffer_s* tb)
     }
     ac->blasNeed = maxBlasCoop;
     ac->blasNeedAny = maxBlasAny;
+    ac->sbtOffsets = sbtOffsets;
     ac->nWide = (uint32_t)dW.size();
     // per-lane kernels: [need][64 lanes] words of LDS per wave, 64 KB at most
     if (ac->stackNeed > 250) return fail("BVH too deep for the LDS traversal stack: %u entries per ray needed, 250 available", ac->stackNeed);
@@ -434,12 +440,12 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.tnodes = tb->accel->tnodes; v.ctnodes = tb->accel->ctnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
     v.wide = tb->accel->wide;
     v.status = g.dStatus;
-    v.kernel = (g.kernel >= 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
+    v.kernel = tb->accel->sbtOffsets ? 0u : (g.kernel >= 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
     v.stackNeed = tb->accel->stackNeed;
     v.coopNeed = tb->accel->coopNeed;
     // culled walk: measured +11 % (262 k triangles) / +26 % (10.4 M) frame rate, -2 % on the 20 k-triangle sample1 scene, whose
     // leaves are cheap and whose rays mostly end in quads handled inside the top-level step -- hence the size rule
-    v.cull = (g.kernel == 3 && (g.cull > 0 || (g.cull < 0 && tb->accel->nWide >= 16384u))) ? 1u : 0u;
+    v.cull = (v.kernel == 3 && (g.cull > 0 || (g.cull < 0 && tb->accel->nWide >= 16384u))) ? 1u : 0u;
     v.topNeed = tb->accel->topNeed; v.blasNeed = v.cull ? tb->accel->blasNeedAny : tb->accel->blasNeed;
     v.topFlat = g.topFlat ? tb->accel->topFlat : 0u;
     if (v.topFlat) v.topNeed = std::max(v.topNeed, tb->accel->topFlatNeed);

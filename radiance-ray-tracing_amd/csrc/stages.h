@@ -10,7 +10,10 @@
 #include "device_math.h"
 #include "kernels.h"
 #include "rdx_types.h"
-#include "sbt_generated.h"
+#ifndef RDX_SBT_HEADER
+#define RDX_SBT_HEADER "sbt_generated.h"      // tools/genSBT.py output for samples/sbt.json; a build for another table defines this
+#endif
+#include RDX_SBT_HEADER
 
 namespace rdx {
 

@@ -231,13 +231,16 @@ class Scene:
         self.camera = None
         self.sceneProps = None
         self.rtprop = np.zeros((), rd.RayTraceProperties)
+        self.sbt_offsets = {}   # instance number -> SBTOffset (default 0, as the reference's loader writes: sceneBuilder.cpp:302)
 
     def add_mesh(self, mesh):
         self.meshes.append(mesh)
         return len(self.meshes) - 1
 
-    def add_instance(self, mesh_index, transform=None, material_index=0):
+    def add_instance(self, mesh_index, transform=None, material_index=0, sbt_offset=0):
         self.instances.append((mesh_index, np.eye(4, dtype=F) if transform is None else np.asarray(transform, F), material_index))
+        if sbt_offset:
+            self.sbt_offsets[len(self.instances) - 1] = int(sbt_offset)     # instanceShaderBindingTableRecordOffset
 
     @property
     def width(self):
@@ -299,7 +302,7 @@ class DeviceScene:
         self.meshInfoData = up(b["meshInfo"]); self.vertexData = up(b["vertex"]); self.indexData = up(b["index"])
         self.uvData = up(b["uv"]); self.normalData = up(b["normal"]); self.materialData = up(b["material"])
         self.blas = rd.BuildAccelStructs(plt, [rd.Mesh(m[0], m[1]) for m in scene.meshes])
-        insts = [rd.Instance(tf, 0, mat, self.blas[mi]) for (mi, tf, mat) in scene.instances]
+        insts = [rd.Instance(tf, scene.sbt_offsets.get(k, 0), mat, self.blas[mi]) for k, (mi, tf, mat) in enumerate(scene.instances)]
         self.topAccelStruct = rd.BuildAccelStruct(plt, insts)
         self.descSet = rd.CreateDescriptorSet([
             self.rdRTProp, self.rdImageScratch, self.rdImage, self.rdCamData, self.rdSceneData,

@@ -28,7 +28,7 @@ def small_scene(scenes, name, fstop=0.0):
 def scene_blob(rd, scene):
     """TLAS blob of a scenes.Scene through the product's host-only builder (needs no GPU)."""
     blas = rd.BuildAccelStructs(None, [rd.Mesh(m[0], m[1]) for m in scene.meshes])
-    insts = [rd.Instance(tf, 0, mat, blas[mi]) for (mi, tf, mat) in scene.instances]
+    insts = [rd.Instance(tf, scene.sbt_offsets.get(k, 0), mat, blas[mi]) for k, (mi, tf, mat) in enumerate(scene.instances)]
     return rd.BuildTopAccelStructBlob(insts)[0]
 
 

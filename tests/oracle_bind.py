@@ -159,7 +159,7 @@ def tlas_build(instances, blases):
 def scene_tlas(scene):
     """oracle-built TLAS blob for a scenes.Scene"""
     blases = [OracleBlas(m[0], m[1]) for m in scene.meshes]
-    insts = [(mi, tf, 0, mat) for (mi, tf, mat) in scene.instances]
+    insts = [(mi, tf, getattr(scene, "sbt_offsets", {}).get(k, 0), mat) for k, (mi, tf, mat) in enumerate(scene.instances)]
     blob, depth = tlas_build(insts, blases)
     return blob, depth, blases
 

@@ -781,3 +781,41 @@ def test_image_array_and_texture_path(mods):
         assert not np.array_equal(outs[0], stub) and not np.array_equal(outs[0], outs[1])      # the textures are really read
     finally:
         rd.SetOption("textures", 0)
+
+
+def test_instance_sbt_offsets(mods, tmp_path):
+    """dispatch index = instanceSBTOffset + sbtRecordOffset (radiance.cl:281, shader.cl:574-605).
+    (a) stock table, one instance with SBTOffset 1: its radiance-ray hits dispatch row 2 -- closest-hit `shadow` (payload.hit,
+        colour 0, next ray untouched) and any-hit `anyShadow`, which ENDS the walk at the first accepted candidate in the
+        reference's DFS order; shadow rays onto it dispatch row 3, which has no hit shaders.  Such scenes are traced by the
+        reference-order kernel: HitData (incl. the first-candidate rule) and frames equal the CPU oracle's, which keeps the
+        reference's megakernel structure; test_gpu_reference.py repeats it against the reference's own device code.
+    (b) a library built for a two-table sbt.json (tests/golden/sbt_two_tables.json): instances with SBTOffset 4 reach the same
+        shaders through rows 5 / 6 -> frames bit-identical to offset 0."""
+    import subprocess
+    import sys
+    rd, scenes = mods
+    s = scenes.c1_cornell(96, 54, spp=2, depth=4, sphere_subdiv=3)
+    s.sbt_offsets = {5: 1, 7: 1}                       # the tall box and the sphere
+    dev = scenes.DeviceScene(s)
+    blob_o, _, _ = ob.scene_tlas(s)
+    assert rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes() == blob_o
+    osc = ob.OracleScene(s, blob_o)
+    o, d = _ray_batch(osc, 4096, 21)
+    for rec in (1, 2):
+        ref = ob.trace_batch(blob_o, o, d, 0.001, 1000.0, rec)
+        got = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+        assert np.array_equal(_bits(ref), _bits(got)), rec
+    assert (ref["instanceSBTOffset"][ref["hit"] == 1] == 1).sum() > 200
+    for f in range(2):
+        dev.render(); osc.frame()
+        assert _near_oracle(dev.read_scratch(), osc.scratch), f
+    # (b)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "radiance-ray-tracing_amd", "librdx_sbt2.so")
+    if not os.path.exists(lib):
+        env = dict(os.environ, RDX_SBT_JSON=os.path.join(root, "tests", "golden", "sbt_two_tables.json"), RDX_LIB_NAME="librdx_sbt2.so")
+        subprocess.check_call([sys.executable, os.path.join(root, "radiance-ray-tracing_amd", "build.py"), "--force"], env=env, stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sbt_two_tables_check.py")], env=dict(os.environ, RDX_LIB=lib),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

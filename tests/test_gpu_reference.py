@@ -270,3 +270,27 @@ def test_textured_materials_render_like_the_live_reference(mods, ref):
     blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
     rs = rg.RefScene(ref, s, blob)
     _frames_identical(rd, dev, rs, frames=2)
+
+
+def test_instance_sbt_offset_like_the_reference(mods, ref):
+    """stock table, instances with SBTOffset 1 (see test_gpu_parity.test_instance_sbt_offsets): HitData of closest-hit and
+    any-hit batches -- the first-accepted-candidate rule of a terminating any-hit shader included -- bit-identical to the
+    reference's own intersectTop.  (Frames are not compared: a shadow ray that hits such an instance dispatches row 3, which
+    has no hit shader, and the reference then reads `shadowPayload.hit` uninitialised -- shader.cl:497-503 -- so its picture
+    is undefined there; the product and the oracle define it as "not occluded".)"""
+    rd, scenes = mods
+    s = scenes.c1_cornell(160, 90, spp=2, depth=4, sphere_subdiv=3)
+    s.sbt_offsets = {5: 1, 7: 1}
+    dev = scenes.DeviceScene(s)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    rs = rg.RefScene(ref, s, blob)
+    npix = s.width * s.height
+    sel = gc.spread(npix, 3000)
+    po, pd = rd.GenerateBatch(sel.astype(np.uint32), gc.generate_inputs(sel.shape[0], 5))
+    ph = rd.TraceBatch(dev.topAccelStruct, po, pd)
+    o, d = gc.derived_rays(23, po, pd, ph["hit"], ph["distance"])
+    for rec in (1, 2):
+        r = rs.trace(o, d, 0.001, 1000.0, rec)
+        g = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+        _same_hits(r, g, closest=True, tag="rec %d" % rec)
+    assert (r["instanceSBTOffset"][r["hit"] == 1] == 1).sum() > 100
