@@ -33,6 +33,10 @@ struct CLContext
     {
         static CLContext ctx;
         if (rdx_init(-1) != 0) { printf("Radiance Error: %s\n", rdx_last_error()); exit(-1); }
+        // RDX_DEVICES=<n>: an unchanged caller (samples/sample1.cpp) renders every TraceRays frame on n GPUs of the node
+        // (rdx_init_devices: buffers replicated, frame sharded by image tiles, gathered to device 0 before TraceRays returns)
+        if (const char* nd = getenv("RDX_DEVICES"))
+            if (atoi(nd) > 1 && rdx_init_devices((uint32_t)atoi(nd), nullptr) != 0) { printf("Radiance Error: %s\n", rdx_last_error()); exit(-1); }
         return &ctx;
     }
     void Cleanup() { rdx_shutdown(); }

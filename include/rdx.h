@@ -44,6 +44,14 @@ typedef struct rdx_instance {
 /* ---- platform: replaces RD::Platform::GetPlatform / CLContext::GetCLContext
  *      (radiance.h:146-174, radiance/src/clcontext.cpp:12-40) */
 int         rdx_init(int device_ordinal);            /* idempotent; -1 = current device */
+/* Single-process multi-device rendering (no reference counterpart: the reference is single-device, clcontext.cpp:17-36).  After
+ * this call every buffer is replicated on `n` devices (writes go to all, reads come from logical device 0) and rdx_trace_rays
+ * shards the frame by interleaved 64x64 image tiles over them -- one internal host thread per device, the caller still makes
+ * one blocking call -- and copies every device's RGBA8 and imageScratch tiles into device 0's buffers before it returns.
+ * ordinals[i] = HIP device of logical device i (NULL: consecutive devices starting at the one rdx_init chose).  Call before
+ * creating buffers.  Results are bit-identical to one device (pixel / RNG indices stay global). */
+int         rdx_init_devices(uint32_t n, const int* ordinals);
+int         rdx_device_count(void);
 int         rdx_shutdown(void);
 const char* rdx_last_error(void);
 int         rdx_device_name(char* out, size_t cap);

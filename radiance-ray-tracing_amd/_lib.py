@@ -59,6 +59,8 @@ class rdx_payload(C.Structure):
 # name -> (restype, argtypes); must list every symbol of include/rdx.h (tests check this)
 SIGNATURES = {
     "rdx_init": (C.c_int, [C.c_int]),
+    "rdx_init_devices": (C.c_int, [C.c_uint32, C.POINTER(C.c_int)]),
+    "rdx_device_count": (C.c_int, []),
     "rdx_shutdown": (C.c_int, []),
     "rdx_last_error": (C.c_char_p, []),
     "rdx_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),

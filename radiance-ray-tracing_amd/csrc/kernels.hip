@@ -1181,7 +1181,7 @@ static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsByte
 }
 uint32_t coop_lds_words(uint32_t coopNeed) { return coop_words_per_wave(coopNeed); }
 uint32_t pool_lds_words(uint32_t topNeed, uint32_t blasNeed) { return pool_words_per_wave(topNeed, blasNeed); }
-static uint32_t g_gridShare = 1;       // host side: how many concurrent persistent launches share the GPU (set per chunk)
+static thread_local uint32_t g_gridShare = 1;       // host side: how many concurrent persistent launches share the GPU (set per chunk)
 void set_grid_share(uint32_t groups) { g_gridShare = groups ? groups : 1; }
 
 // persistent grid: enough blocks to fill every CU at the LDS-limited residency, never more than the work

@@ -31,6 +31,7 @@ using namespace rdx;
 // ------------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------------
+constexpr int RDX_MAX_DEVICES = 16;
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
     DNode* tnodes = nullptr; DNode* ctnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
@@ -71,6 +72,10 @@ struct rdx_buffer_s {
     std::vector<uint8_t> mirror;
     bool mirrorValid = false;
     uint32_t imgW = 0, imgH = 0, imgLayers = 0;   // != 0: an RGBA8 image array created by rdx_image_array_create
+    // single-process multi-device mode (rdx_init_devices): the copy of this buffer on logical device d >= 1 and the traversal
+    // layout derived from it there; device 0 uses dptr / accel
+    void* rep[RDX_MAX_DEVICES] = {};
+    std::unique_ptr<AccelCache> accelRep[RDX_MAX_DEVICES];
 };
 struct rdx_sampler_s { uint32_t addressing = 0, filter = 0; };
 struct rdx_blas_s { std::unique_ptr<Blas> blas; };
@@ -110,6 +115,8 @@ struct Context {
     size_t sampleCap = 0;
     float4* sampleColor = nullptr;
     uint32_t* dCounts = nullptr;            // = groups[0].dCounts (test seams)
+    void* gatherStage[4] = {};              // multi-device gather: packed tiles (RGBA8, imageScratch) on this device and their landing buffers on device 0
+    size_t gatherCap[4] = {};
     uint32_t* hStatus = nullptr;            // pinned, device-mapped: bit 0 = a traversal wave hit its iteration bound
     uint32_t* dStatus = nullptr;            // its device address
     int groupsOpt = 0;                      // sample groups in flight: 1..4, 0 = two for chunks small enough to be ramp + drain bound
@@ -128,10 +135,26 @@ struct Context {
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
     rdx_trace_stats stats{};
+    float camAngles[3] = {0, 0, 0}, camTrig[6] = {1, 0, 1, 0, 1, 0};      // camera_args: cos / sin of the camera angles, evaluated on the device
+    bool camCached = false;
     uint32_t visitDepth = 0;                // bounces covered by hVisit after a count_visits frame
     uint64_t bounceCounts[65] = {};         // [d] = closest-hit rays of bounce d, [d+1] = hits = shadow rays of bounce d (last frame)
 };
-Context g;
+// The process has one Context per LOGICAL device.  g0 is device 0 and also the registry (buffers, shaders, descriptor slots,
+// options).  Every function below reads `g`, which is the context of the calling thread: g0 on the caller's thread; inside
+// rdx_trace_rays in multi-device mode each worker thread points it at its own device's context (streams, path buffers, counters,
+// shard) after copying the registry-side fields it needs (slots, pipeline, options).
+Context g0;
+Context* g_dev[RDX_MAX_DEVICES] = {&g0};     // logical device -> context (entries >= 1 are heap-allocated by rdx_init_devices)
+int g_phys[RDX_MAX_DEVICES] = {0};           // logical device -> HIP device ordinal
+int g_ndev = 1;
+thread_local Context* tl_ctx = &g0;
+thread_local int tl_dev = 0;                 // logical device of the calling thread
+#define g (*tl_ctx)
+
+inline void* dp(const rdx_buffer_s* b) { return tl_dev == 0 ? b->dptr : b->rep[tl_dev]; }
+inline std::unique_ptr<AccelCache>& acc(rdx_buffer_s* b) { return tl_dev == 0 ? b->accel : b->accelRep[tl_dev]; }
+inline const std::unique_ptr<AccelCache>& acc(const rdx_buffer_s* b) { return tl_dev == 0 ? b->accel : b->accelRep[tl_dev]; }
 
 int fail(const char* fmt, ...)
 {
@@ -145,7 +168,7 @@ int fail(const char* fmt, ...)
 
 bool known_buffer(const void* h)
 {
-    for (auto& b : g.buffers) if (b.get() == h) return true;
+    for (auto& b : g0.buffers) if (b.get() == h) return true;
     return false;
 }
 
@@ -171,7 +194,7 @@ uint32_t blas_need(const BlobNode* nodes, uint32_t idx)
 
 int derive_accel(rdx_buffer_s* tb)
 {
-    if (tb->accel && tb->accel->version == tb->version) return 0;
+    if (acc(tb) && acc(tb)->version == tb->version) return 0;
     // host copy of the blob
     if (tb->shadowVersion != tb->version) {
         tb->shadow.resize(tb->size);
@@ -429,27 +452,27 @@ int derive_accel(rdx_buffer_s* tb)
         std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u = top %u + BLAS %u)\n",
                      nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed, ac->topNeed, ac->blasNeed);
     ac->version = tb->version;
-    if (tb->accel) tb->accel->release();
-    tb->accel = std::move(ac);
+    if (acc(tb)) acc(tb)->release();
+    acc(tb) = std::move(ac);
     return 0;
 }
 
 AccelView view_of(const rdx_buffer_s* tb)
 {
     AccelView v{};
-    v.tnodes = tb->accel->tnodes; v.ctnodes = tb->accel->ctnodes; v.insts = tb->accel->insts; v.bnodes = tb->accel->bnodes; v.tris = tb->accel->tris;
-    v.wide = tb->accel->wide;
+    v.tnodes = acc(tb)->tnodes; v.ctnodes = acc(tb)->ctnodes; v.insts = acc(tb)->insts; v.bnodes = acc(tb)->bnodes; v.tris = acc(tb)->tris;
+    v.wide = acc(tb)->wide;
     v.status = g.dStatus;
-    v.kernel = tb->accel->sbtOffsets ? 0u : (g.kernel >= 2 && !tb->accel->coopOK) ? 1u : (uint32_t)g.kernel;
-    v.stackNeed = tb->accel->stackNeed;
-    v.coopNeed = tb->accel->coopNeed;
+    v.kernel = acc(tb)->sbtOffsets ? 0u : (g.kernel >= 2 && !acc(tb)->coopOK) ? 1u : (uint32_t)g.kernel;
+    v.stackNeed = acc(tb)->stackNeed;
+    v.coopNeed = acc(tb)->coopNeed;
     // culled walk: measured +11 % (262 k triangles) / +26 % (10.4 M) frame rate, -2 % on the 20 k-triangle sample1 scene, whose
     // leaves are cheap and whose rays mostly end in quads handled inside the top-level step -- hence the size rule
-    v.cull = (v.kernel == 3 && (g.cull > 0 || (g.cull < 0 && tb->accel->nWide >= 16384u))) ? 1u : 0u;
-    v.topNeed = tb->accel->topNeed; v.blasNeed = v.cull ? tb->accel->blasNeedAny : tb->accel->blasNeed;
-    v.topFlat = g.topFlat ? tb->accel->topFlat : 0u;
-    if (v.topFlat) v.topNeed = std::max(v.topNeed, tb->accel->topFlatNeed);
-    v.leafRoots = (v.topFlat && g.inlineLeafRoots && tb->accel->leafRoots) ? 1u : 0u;
+    v.cull = (v.kernel == 3 && (g.cull > 0 || (g.cull < 0 && acc(tb)->nWide >= 16384u))) ? 1u : 0u;
+    v.topNeed = acc(tb)->topNeed; v.blasNeed = v.cull ? acc(tb)->blasNeedAny : acc(tb)->blasNeed;
+    v.topFlat = g.topFlat ? acc(tb)->topFlat : 0u;
+    if (v.topFlat) v.topNeed = std::max(v.topNeed, acc(tb)->topFlatNeed);
+    v.leafRoots = (v.topFlat && g.inlineLeafRoots && acc(tb)->leafRoots) ? 1u : 0u;
     return v;
 }
 
@@ -515,8 +538,7 @@ int camera_args(const PhysicalCamera& cam, CameraArgs& C)
     // EulerX/Y/ZToMat4x4 (math.cl:185-252): per-frame constants.  cos / sin are evaluated ON THE DEVICE (k_euler_trig) so
     // that they are the OCML values the reference's own cos() / sin() give on this GPU -- libm's differ in the last bit
     // and every primary ray would with them; the six values are cached until the camera angles change.
-    static float cachedAngles[3] = {0, 0, 0}, cachedTrig[6] = {1, 0, 1, 0, 1, 0};
-    static bool cached = false;
+    float (&cachedAngles)[3] = g.camAngles; float (&cachedTrig)[6] = g.camTrig; bool& cached = g.camCached;
     if (!cached || std::memcmp(cachedAngles, &cam.wx, 12) != 0) {
         float* d6 = nullptr;
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&d6), 6 * sizeof(float)));
@@ -541,7 +563,7 @@ int scene_args(SceneArgs& sc)
 {
     for (int i : {4, 5, 7, 8, 9, 10})
         if (!g.slots[i] || !known_buffer(g.slots[i])) return fail("descriptor slot %d is not a buffer", i);
-    auto ptr = [&](int i) { return static_cast<rdx_buffer_s*>(g.slots[i])->dptr; };
+    auto ptr = [&](int i) { return dp(static_cast<rdx_buffer_s*>(g.slots[i])); };
     sc.scene = static_cast<const SceneProperties*>(ptr(4));
     sc.meshInfo = static_cast<const MeshInfo*>(ptr(5));
     sc.indexData = static_cast<const uint32_t*>(ptr(7));
@@ -562,7 +584,7 @@ int scene_args(SceneArgs& sc)
                          : sm->addressing == 0x1134 ? TEX_ADDR_MIRRORED : TEX_ADDR_REPEAT;
                     linear = sm->filter == 0x1141 ? TEX_LINEAR : 0u;
                 }
-            sc.tex = TexView{static_cast<const uint8_t*>(img->dptr), img->imgW, img->imgH, img->imgLayers, TEX_ENABLED | linear | (mode << TEX_ADDR_SHIFT)};
+            sc.tex = TexView{static_cast<const uint8_t*>(dp(img)), img->imgW, img->imgH, img->imgLayers, TEX_ENABLED | linear | (mode << TEX_ADDR_SHIFT)};
         }
     }
     return 0;
@@ -588,23 +610,16 @@ struct StageTimer {
         spans.clear(); used = 0;
     }
 };
-StageTimer g_timer;
+thread_local StageTimer g_timer;
 
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
 // platform
 // ------------------------------------------------------------------------------------------------
-extern "C" int rdx_init(int device)
+// streams, events, counters of the calling thread's context `g` on HIP device `device` (which must be current)
+static int init_device_state(int device)
 {
-    if (g.initialized) return 0;
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count == 0)
-        return fail("no HIP device available (hipGetDeviceCount -> %d, count %d): the ray-tracing core needs a GPU", (int)e, count);
-    if (device < 0) { HIP_OK(hipGetDevice(&device)); }
-    if (device >= count) return fail("device ordinal %d out of range (%d devices)", device, count);
-    HIP_OK(hipSetDevice(device));
     g.device = device;
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&g.evA));
@@ -633,12 +648,11 @@ extern "C" int rdx_init(int device)
     return 0;
 }
 
-extern "C" int rdx_shutdown(void)
+static void release_device_state()
 {
-    if (!g.initialized) return 0;
+    if (!g.initialized) return;
+    HIP_IGN(hipSetDevice(g.device));
     HIP_IGN(hipStreamSynchronize(g.stream));
-    for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
-    g.buffers.clear(); g.blases.clear(); g.shaders.clear();
     for (int k = 0; k < Context::MAX_GROUPS; ++k) {
         Context::Group& G = g.groups[k];
         float4** arr[] = {&G.ps.rayO, &G.ps.rayD, &G.ps.thr, &G.ps.col, &G.ps.hitA, &G.ps.nRayO, &G.ps.nRayD, &G.ps.nThr,
@@ -654,12 +668,93 @@ extern "C" int rdx_shutdown(void)
     }
     if (g.sampleColor) HIP_IGN(hipFree(g.sampleColor));
     if (g.ownedPixels) HIP_IGN(hipFree(g.ownedPixels));
+    for (void* p : g.gatherStage) if (p) HIP_IGN(hipFree(p));
     if (g.hStatus) HIP_IGN(hipHostFree(g.hStatus));
     g.hStatus = nullptr; g.dStatus = nullptr;
     if (g.dVisit) HIP_IGN(hipFree(g.dVisit));
     if (g.hVisit) HIP_IGN(hipHostFree(g.hVisit));
     HIP_IGN(hipEventDestroy(g.evA)); HIP_IGN(hipEventDestroy(g.evB)); HIP_IGN(hipEventDestroy(g.evChunk));
     HIP_IGN(hipStreamDestroy(g.stream));
+}
+
+extern "C" int rdx_init(int device)
+{
+    if (g0.initialized) return 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail("no HIP device available (hipGetDeviceCount -> %d, count %d): the ray-tracing core needs a GPU", (int)e, count);
+    if (device < 0) { HIP_OK(hipGetDevice(&device)); }
+    if (device >= count) return fail("device ordinal %d out of range (%d devices)", device, count);
+    HIP_OK(hipSetDevice(device));
+    g_phys[0] = device;
+    g_ndev = 1;
+    return init_device_state(device);
+}
+
+// Single-process multi-device rendering (SURVEY 8b "Threading", 8e): after this call every buffer lives on all `n` devices
+// (writes are replicated, reads come from device 0) and rdx_trace_rays renders the frame sharded by interleaved 64x64 tiles --
+// one internal host thread per device, the caller still makes one blocking call -- then gathers RGBA8 and imageScratch tiles
+// to device 0 with peer copies.  ordinals[i] = HIP device of logical device i (NULL: 0..n-1); logical device 0 is the one
+// rdx_init chose.  Must be called before any buffer is created.  RDX_ALLOW_VIRTUAL_DEVICES=1 lets several logical devices
+// share one GPU (rehearsal on a 1-GPU box; results are identical by construction).
+extern "C" int rdx_init_devices(uint32_t n, const int* ordinals)
+{
+    if (!g0.initialized && rdx_init(ordinals ? ordinals[0] : -1)) return -1;
+    if (n == 0 || n > (uint32_t)RDX_MAX_DEVICES) return fail("rdx_init_devices: %u devices (1..%d supported)", n, RDX_MAX_DEVICES);
+    if (g_ndev > 1) return (uint32_t)g_ndev == n ? 0 : fail("rdx_init_devices: already initialised with %d devices", g_ndev);
+    if (n == 1) return 0;
+    if (!g0.buffers.empty()) return fail("rdx_init_devices must be called before any buffer is created");
+    int count = 0;
+    HIP_OK(hipGetDeviceCount(&count));
+    const bool virt = std::getenv("RDX_ALLOW_VIRTUAL_DEVICES") && std::atoi(std::getenv("RDX_ALLOW_VIRTUAL_DEVICES")) != 0;
+    for (uint32_t d = 1; d < n; ++d) {
+        int phys = ordinals ? ordinals[d] : (int)((g_phys[0] + d) % (uint32_t)count);
+        if (phys < 0 || phys >= count) return fail("rdx_init_devices: HIP device %d does not exist (%d devices)", phys, count);
+        for (uint32_t e = 0; e < d && !virt; ++e)
+            if (g_phys[e] == phys) return fail("rdx_init_devices: %u devices requested, %d present (set RDX_ALLOW_VIRTUAL_DEVICES=1 to let logical devices share a GPU)", n, count);
+        g_phys[d] = phys;
+    }
+    for (uint32_t d = 1; d < n; ++d) {
+        g_dev[d] = new Context();
+        tl_ctx = g_dev[d]; tl_dev = (int)d;
+        hipError_t e = hipSetDevice(g_phys[d]);
+        int rc = e == hipSuccess ? init_device_state(g_phys[d]) : -1;
+        if (rc == 0 && g_phys[d] != g_phys[0]) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, g_phys[0], g_phys[d]) == hipSuccess && can) {
+                HIP_IGN(hipSetDevice(g_phys[0])); HIP_IGN(hipDeviceEnablePeerAccess(g_phys[d], 0)); (void)hipGetLastError();
+            }
+        }
+        std::string msg = g.err;
+        tl_ctx = &g0; tl_dev = 0;
+        HIP_IGN(hipSetDevice(g_phys[0]));
+        if (rc) return fail("rdx_init_devices: device %u (HIP %d): %s", d, g_phys[d], msg.c_str());
+    }
+    g_ndev = (int)n;
+    return 0;
+}
+
+extern "C" int rdx_device_count(void) { return g_ndev; }
+
+extern "C" int rdx_shutdown(void)
+{
+    if (!g0.initialized) return 0;
+    for (int d = 1; d < g_ndev; ++d) {
+        tl_ctx = g_dev[d]; tl_dev = d;
+        HIP_IGN(hipSetDevice(g_phys[d]));
+        for (auto& b : g0.buffers) { if (b->accelRep[d]) b->accelRep[d]->release(); if (b->rep[d]) HIP_IGN(hipFree(b->rep[d])); }
+        release_device_state();
+        tl_ctx = &g0; tl_dev = 0;
+        delete g_dev[d];
+        g_dev[d] = nullptr;
+    }
+    g_ndev = 1;
+    HIP_IGN(hipSetDevice(g_phys[0]));
+    HIP_IGN(hipStreamSynchronize(g.stream));
+    for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
+    g.buffers.clear(); g.blases.clear(); g.shaders.clear();
+    release_device_state();
     g = Context{};
     return 0;
 }
@@ -685,6 +780,13 @@ extern "C" rdx_buffer rdx_buffer_create(size_t size)
     b->size = size;
     HIP_OKP(hipMalloc(&b->dptr, std::max<size_t>(size, 16)));
     HIP_OKP(hipMemset(b->dptr, 0, std::max<size_t>(size, 16)));
+    for (int d = 1; d < g_ndev; ++d) {          // multi-device mode: one copy per device
+        HIP_OKP(hipSetDevice(g_phys[d]));
+        hipError_t e = hipMalloc(&b->rep[d], std::max<size_t>(size, 16));
+        if (e == hipSuccess) e = hipMemset(b->rep[d], 0, std::max<size_t>(size, 16));
+        HIP_IGN(hipSetDevice(g_phys[0]));
+        HIP_OKP(e);
+    }
     g.buffers.push_back(std::move(b));
     return g.buffers.back().get();
 }
@@ -715,6 +817,13 @@ extern "C" int rdx_image_write(rdx_buffer img, uint32_t width, uint32_t height, 
     if (!width || !height) return 0;
     uint8_t* dst = static_cast<uint8_t*>(img->dptr) + layer * (size_t)img->imgW * img->imgH * 4;
     HIP_OK(hipMemcpy2D(dst, (size_t)img->imgW * 4, rgba8, (size_t)width * 4, (size_t)width * 4, height, hipMemcpyHostToDevice));
+    for (int d = 1; d < g_ndev; ++d) {
+        HIP_OK(hipSetDevice(g_phys[d]));
+        hipError_t e = hipMemcpy2D(static_cast<uint8_t*>(img->rep[d]) + layer * (size_t)img->imgW * img->imgH * 4, (size_t)img->imgW * 4, rgba8,
+                                   (size_t)width * 4, (size_t)width * 4, height, hipMemcpyHostToDevice);
+        HIP_IGN(hipSetDevice(g_phys[0]));
+        HIP_OK(e);
+    }
     ++img->version;
     return 0;
 }
@@ -745,6 +854,7 @@ extern "C" rdx_buffer rdx_buffer_wrap(void* device_ptr, size_t size)
     if (!g.initialized) { fail("rdx_init has not been called"); return nullptr; }
     if (!device_ptr) { fail("rdx_buffer_wrap: null device pointer"); return nullptr; }
     auto b = std::make_unique<rdx_buffer_s>();
+    if (g_ndev > 1) { fail("rdx_buffer_wrap: caller-owned device memory cannot be replicated in multi-device mode"); return nullptr; }
     b->size = size; b->dptr = device_ptr; b->owned = false;
     g.buffers.push_back(std::move(b));
     return g.buffers.back().get();
@@ -755,6 +865,12 @@ extern "C" int rdx_buffer_write(rdx_buffer b, size_t offset, size_t size, const 
     if (!b || !known_buffer(b)) return fail("WriteBuffer: invalid buffer handle");
     if (offset + size > b->size) return fail("WriteBuffer: range [%zu, %zu) exceeds buffer size %zu", offset, offset + size, b->size);
     if (size) HIP_OK(hipMemcpy(static_cast<uint8_t*>(b->dptr) + offset, src, size, hipMemcpyHostToDevice));
+    for (int d = 1; d < g_ndev && size; ++d) {   // replicate
+        HIP_OK(hipSetDevice(g_phys[d]));
+        hipError_t e = hipMemcpy(static_cast<uint8_t*>(b->rep[d]) + offset, src, size, hipMemcpyHostToDevice);
+        HIP_IGN(hipSetDevice(g_phys[0]));
+        HIP_OK(e);
+    }
     b->version++;
     if (b->owned && b->size <= 256) {
         if (offset == 0 && size == b->size) { b->mirror.assign(static_cast<const uint8_t*>(src), static_cast<const uint8_t*>(src) + size); b->mirrorValid = true; }
@@ -1034,7 +1150,7 @@ static int pack_impl(rdx_buffer image, rdx_buffer packed, uint32_t w, uint32_t h
     const uint32_t owned = nT > rank ? (nT - rank + world - 1) / world : 0;
     if ((size_t)w * h * elem > image->size) return fail("pack_tiles: image buffer too small");
     if ((size_t)owned * g.tileW * g.tileH * elem > packed->size) return fail("pack_tiles: packed buffer too small");
-    launch_pack_tiles(g.stream, static_cast<uint8_t*>(image->dptr), static_cast<uint8_t*>(packed->dptr), w, h, elem,
+    launch_pack_tiles(g.stream, static_cast<uint8_t*>(dp(image)), static_cast<uint8_t*>(dp(packed)), w, h, elem,
                       g.tileW, g.tileH, rank, world, unpack);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));
@@ -1109,7 +1225,8 @@ extern "C" int rdx_get_visit_profile(uint64_t* out, uint32_t max_bounces)
 
 extern "C" int rdx_get_trace_stats(rdx_trace_stats* out) { if (!out) return fail("null"); *out = g.stats; return 0; }
 
-extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint32_t height)
+// one frame on the calling thread's device (context `g`, logical device tl_dev): every pixel of its shard
+static int trace_rays_device(uint32_t width, uint32_t height)
 {
     if (!g.initialized) return fail("rdx_init has not been called");
     if (!g.pipeline) return fail("TraceRays: no pipeline bound");
@@ -1136,9 +1253,9 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
     // per-frame constants live in device buffers the caller may have rewritten (sample1.cpp:480-490)
     RayTraceProperties rt; PhysicalCamera cam;
     if (bRT->mirrorValid && bRT->mirror.size() >= sizeof rt) std::memcpy(&rt, bRT->mirror.data(), sizeof rt);
-    else HIP_OK(hipMemcpy(&rt, bRT->dptr, sizeof rt, hipMemcpyDeviceToHost));
+    else HIP_OK(hipMemcpy(&rt, dp(bRT), sizeof rt, hipMemcpyDeviceToHost));
     if (bCam->mirrorValid && bCam->mirror.size() >= sizeof cam) std::memcpy(&cam, bCam->mirror.data(), sizeof cam);
-    else HIP_OK(hipMemcpy(&cam, bCam->dptr, sizeof cam, hipMemcpyDeviceToHost));
+    else HIP_OK(hipMemcpy(&cam, dp(bCam), sizeof cam, hipMemcpyDeviceToHost));
     CameraArgs C;
     if (camera_args(cam, C)) return -1;
     if ((uint32_t)cam.widthPixel == 0) return fail("TraceRays: camera widthPixel is 0");
@@ -1201,7 +1318,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
             g_timer.end();
             g_timer.begin(&g.stats.ms_accumulate);
             launch_accumulate(g.stream, G.ps, owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
-                              static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
+                              static_cast<float*>(dp(bScratch)), static_cast<uint8_t*>(dp(bImage)));
             g_timer.end();
             HIP_OK(hipMemcpyAsync(G.hCounts, G.dCounts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
             HIP_OK(hipStreamSynchronize(g.stream));
@@ -1290,7 +1407,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         }
         g_timer.begin(&g.stats.ms_accumulate);
         launch_accumulate(g.stream, gps[0], owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
-                          static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
+                          static_cast<float*>(dp(bScratch)), static_cast<uint8_t*>(dp(bImage)));
         g_timer.end();
         HIP_OK(hipStreamSynchronize(g.stream));
         for (int k = 0; k < nGroups; ++k) {
@@ -1305,7 +1422,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         // no samples: only the tonemap of the existing accumulator runs (shader.cl:283-304)
         PathStreams none{};
         launch_accumulate(g.stream, none, owned, P, 0, 0, rt.totalSamples, true, rt.debug,
-                          static_cast<float*>(bScratch->dptr), static_cast<uint8_t*>(bImage->dptr));
+                          static_cast<float*>(dp(bScratch)), static_cast<uint8_t*>(dp(bImage)));
     }
     HIP_OK(hipEventRecord(g.evB, g.stream));
     if (visit) HIP_OK(hipMemcpyAsync(g.hVisit, g.dVisit, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
@@ -1328,6 +1445,116 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
             }
     }
     bScratch->version++; bImage->version++;
+    return 0;
+}
+
+static int ensure_stage(int slot, size_t bytes)
+{
+    if (g.gatherCap[slot] >= bytes) return 0;
+    if (g.gatherStage[slot]) HIP_IGN(hipFree(g.gatherStage[slot]));
+    g.gatherStage[slot] = nullptr; g.gatherCap[slot] = 0;
+    HIP_OK(hipMalloc(&g.gatherStage[slot], std::max<size_t>(bytes, 16)));
+    g.gatherCap[slot] = bytes;
+    return 0;
+}
+
+// RD::TraceRays (radiance.cpp:242-267).  One device: the frame.  n devices (rdx_init_devices): the frame sharded by interleaved
+// 64x64 tiles -- one internal host thread per device drives that device's streams, the caller's single blocking call returns
+// when every shard is done and its RGBA8 + imageScratch tiles have been copied into device 0's buffers (peer copies over xGMI;
+// no collective library is needed inside one process), where ReadBuffer reads them.
+extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint32_t height)
+{
+    if (g_ndev <= 1) return trace_rays_device(width, height);
+    if (!g0.initialized) return fail("rdx_init has not been called");
+    if (g0.world > 1) return fail("TraceRays: rdx_set_shard and rdx_init_devices cannot be combined");
+    if (g0.nslots < 14 || !g0.slots[13] || !known_buffer(g0.slots[13]) || !g0.slots[1] || !known_buffer(g0.slots[1]) ||
+        !g0.slots[2] || !known_buffer(g0.slots[2]))
+        return trace_rays_device(width, height);       // reports the binding error
+    auto* bScratch = static_cast<rdx_buffer_s*>(g0.slots[1]);
+    auto* bImage = static_cast<rdx_buffer_s*>(g0.slots[2]);
+    auto* bTlas = static_cast<rdx_buffer_s*>(g0.slots[13]);
+    const int n = g_ndev;
+    // registry-side state each device context needs, and the derived traversal layout on every device (sequentially: the host
+    // copy of the blob is shared)
+    for (int d = 1; d < n; ++d) {
+        Context& c = *g_dev[d];
+        std::memcpy(c.slots, g0.slots, sizeof c.slots);
+        c.nslots = g0.nslots; c.pipeline = g0.pipeline;
+        c.groupsOpt = g0.groupsOpt; c.fuse = g0.fuse; c.pathMode = g0.pathMode; c.chunkPaths = g0.chunkPaths;
+        c.countVisits = g0.countVisits; c.profiling = g0.profiling; c.inlineLeafRoots = g0.inlineLeafRoots; c.cull = g0.cull;
+        c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap;
+    }
+    for (int d = 0; d < n; ++d) {
+        tl_ctx = g_dev[d]; tl_dev = d;
+        hipError_t e = hipSetDevice(g_phys[d]);
+        const int rc = e == hipSuccess ? derive_accel(bTlas) : -1;
+        const std::string msg = g.err;
+        tl_ctx = &g0; tl_dev = 0;
+        HIP_IGN(hipSetDevice(g_phys[0]));
+        if (rc) return fail("device %d: %s", d, e == hipSuccess ? msg.c_str() : hipGetErrorString(e));
+    }
+    std::vector<int> rcs(n, 0);
+    std::vector<std::string> msgs(n);
+    auto work = [&](int d) {
+        tl_ctx = g_dev[d]; tl_dev = d;
+        if (hipSetDevice(g_phys[d]) != hipSuccess) { rcs[d] = -1; msgs[d] = "hipSetDevice failed"; return; }
+        g.rank = (uint32_t)d; g.world = (uint32_t)n; g.tileW = 64; g.tileH = 64;
+        rcs[d] = trace_rays_device(width, height);
+        if (rcs[d]) msgs[d] = g.err;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int d = 1; d < n; ++d) pool.emplace_back(work, d);
+        work(0);
+        for (auto& t : pool) t.join();
+    }
+    tl_ctx = &g0; tl_dev = 0;
+    g0.rank = 0; g0.world = 1;
+    HIP_OK(hipSetDevice(g_phys[0]));
+    for (int d = 0; d < n; ++d) if (rcs[d]) return fail("device %d: %s", d, msgs[d].c_str());
+    // gather: device d's tiles -> device 0 (image and the running-mean accumulator)
+    const uint32_t tilesX = (width + 63) / 64, tilesY = (height + 63) / 64, nTiles = tilesX * tilesY;
+    for (int d = 1; d < n; ++d) {
+        const uint32_t owned = nTiles > (uint32_t)d ? (nTiles - d + n - 1) / n : 0;
+        if (!owned) continue;
+        const size_t bytes[2] = {(size_t)owned * 64 * 64 * 4, (size_t)owned * 64 * 64 * 16};
+        const uint32_t elem[2] = {4, 16};
+        rdx_buffer_s* src[2] = {bImage, bScratch};
+        for (int k = 0; k < 2; ++k) {
+            if (ensure_stage(2 + k, bytes[k])) return -1;                      // landing buffer on device 0
+            void* land = g0.gatherStage[2 + k];
+            tl_ctx = g_dev[d]; tl_dev = d;
+            hipError_t e = hipSetDevice(g_phys[d]);
+            int rc = e == hipSuccess ? ensure_stage(k, bytes[k]) : -1;
+            void* stage = g.gatherStage[k];
+            if (!rc) {
+                launch_pack_tiles(g.stream, static_cast<uint8_t*>(src[k]->rep[d]), static_cast<uint8_t*>(stage), width, height, elem[k], 64, 64,
+                                  (uint32_t)d, (uint32_t)n, false);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = g_phys[d] == g_phys[0] ? hipMemcpyAsync(land, stage, bytes[k], hipMemcpyDeviceToDevice, g.stream)
+                                                                : hipMemcpyPeerAsync(land, g_phys[0], stage, g_phys[d], bytes[k], g.stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+                if (e != hipSuccess) rc = -1;
+            }
+            const std::string msg = rc ? (e != hipSuccess ? std::string(hipGetErrorString(e)) : g.err) : std::string();
+            tl_ctx = &g0; tl_dev = 0;
+            HIP_IGN(hipSetDevice(g_phys[0]));
+            if (rc) return fail("gather from device %d: %s", d, msg.c_str());
+            launch_pack_tiles(g0.stream, static_cast<uint8_t*>(src[k]->dptr), static_cast<uint8_t*>(land), width, height, elem[k], 64, 64,
+                              (uint32_t)d, (uint32_t)n, true);
+            HIP_OK(hipGetLastError());
+            HIP_OK(hipStreamSynchronize(g0.stream));
+        }
+    }
+    // statistics of the whole frame: rays summed over the devices, times = the slowest device
+    for (int d = 1; d < n; ++d) {
+        const rdx_trace_stats& t = g_dev[d]->stats;
+        rdx_trace_stats& a = g0.stats;
+        a.rays_primary += t.rays_primary; a.rays_bounce += t.rays_bounce; a.rays_shadow += t.rays_shadow;
+        a.closest_hits += t.closest_hits; a.pixels += t.pixels;
+        a.ms_total = std::max(a.ms_total, t.ms_total);
+        for (int i = 0; i < 65; ++i) g0.bounceCounts[i] += g_dev[d]->bounceCounts[i];
+    }
     return 0;
 }
 

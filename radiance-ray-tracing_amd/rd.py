@@ -134,6 +134,15 @@ class Platform:
         return p
 
     @staticmethod
+    def InitDevices(n, ordinals=None):
+        """Extension: render every TraceRays frame on `n` devices from this one process (rdx_init_devices); call before any
+        buffer is created.  Returns the platform."""
+        p = Platform.GetPlatform(-1 if ordinals is None else ordinals[0])
+        arr = (C.c_int * n)(*ordinals) if ordinals is not None else None
+        _check(_lib.lib().rdx_init_devices(int(n), arr))
+        return p
+
+    @staticmethod
     def device_name():
         buf = C.create_string_buffer(256)
         _check(_lib.lib().rdx_device_name(buf, 256))

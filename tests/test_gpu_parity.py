@@ -819,3 +819,27 @@ def test_instance_sbt_offsets(mods, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "sbt_two_tables_check.py")], env=dict(os.environ, RDX_LIB=lib),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_single_process_multi_device(mods, tmp_path):
+    """rdx_init_devices (SURVEY 8b "Threading", 8e): one process, N logical devices, one blocking TraceRays call that returns with
+    the gathered frame on device 0.  Only one GPU is present here, so three logical devices share it (RDX_ALLOW_VIRTUAL_DEVICES:
+    own contexts, streams, path buffers and buffer replicas each; the peer copies become same-device copies) -- the scheduler,
+    the replication of writes, the tile gather of image + accumulator and the statistics are exercised, not the xGMI transfer.
+    Two progressive frames must be bit-identical to the one-device render"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "md.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "multi_device_check.py"), "3", out],
+                       env=dict(os.environ, RDX_ALLOW_VIRTUAL_DEVICES="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.load(out)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import multi_device_check as mdc
+    ref = mdc.render(1)
+    for k in ref:
+        assert np.array_equal(_bits(np.asarray(ref[k])), _bits(np.asarray(got[k]))), k
+    # without the override a machine with fewer GPUs refuses instead of silently sharing
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "multi_device_check.py"), "3", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "RDX_ALLOW_VIRTUAL_DEVICES" in (r.stdout + r.stderr)
