@@ -159,6 +159,8 @@ def apply_options(rd, args):
         rd.SetOption("groups", args.groups)
     if args.cull >= 0:
         rd.SetOption("cull", args.cull)
+    if args.sort >= 0:
+        rd.SetOption("sort", args.sort)
     if args.kernel >= 0:
         rd.SetOption("kernel", args.kernel)
         ENGINE = "pool" if args.kernel == 3 else "coop"
@@ -167,7 +169,7 @@ def apply_options(rd, args):
 def option_args(args):
     out = ["--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
            "--depth", str(args.depth), "--fuse", str(args.fuse), "--pipeline", str(args.pipeline), "--kernel", str(args.kernel),
-           "--top-flat", str(args.top_flat), "--groups", str(args.groups), "--cull", str(args.cull)]
+           "--top-flat", str(args.top_flat), "--groups", str(args.groups), "--cull", str(args.cull), "--sort", str(args.sort)]
     return out
 
 
@@ -272,7 +274,7 @@ def cpu_baseline(scene, budget_s=20.0):
                       % (m, int(scene.rtprop["batchSize"]), int(scene.rtprop["depth"]), reps, dt, rays)}
 
 
-STAGE_KEYS = ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulate", "ms_total", "ms_fused", "ms_path")
+STAGE_KEYS = ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulate", "ms_total", "ms_fused", "ms_path", "ms_sort")
 
 
 def main():
@@ -295,6 +297,7 @@ def main():
     ap.add_argument("--top-flat", type=int, default=-1, help="-1 library default; 0/1: evaluate small top-level trees all at once (pool engine)")
     ap.add_argument("--groups", type=int, default=-1, help="-1 library default; 1..4 sample groups of a chunk on their own streams")
     ap.add_argument("--cull", type=int, default=-1, help="-1 library default (automatic); 0 = exhaustive walk, 1 = culled walk (pool engine)")
+    ap.add_argument("--sort", type=int, default=-1, help="-1 library default (automatic); 0 / 1: per-bounce ray sort off / on")
     ap.add_argument("--also", default=None, help="comma list of extra workloads to time (reported under 'also'); default at N=1: the other two")
     args = ap.parse_args()
 
@@ -370,7 +373,7 @@ def main():
         prof_inline = world == 1
         rd.SetProfiling(prof_inline)
         acc = dict(primary=0, bounce=0, shadow=0, hits=0, ms_extend=0.0, ms_shadow=0.0, ms_shade=0.0, ms_generate=0.0,
-                   ms_accumulate=0.0, ms_total=0.0, ms_fused=0.0, ms_path=0.0, launches_extend=0)
+                   ms_accumulate=0.0, ms_total=0.0, ms_fused=0.0, ms_path=0.0, ms_sort=0.0, launches_extend=0)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -489,7 +492,7 @@ def main():
                            "bytes_per_frame": int(frame_bytes)},
         "stage_timing": "HIP events inside the timed region" if world == 1 else
                         "HIP events on 3 extra untimed frames per rank (the timed region runs without per-stage events)",
-        "stage_ms_per_frame": {k[3:]: round(acc[k] / steps, 4) for k in ("ms_generate", "ms_extend", "ms_shade", "ms_shadow", "ms_fused", "ms_path", "ms_accumulate", "ms_total")},
+        "stage_ms_per_frame": {k[3:]: round(acc[k] / steps, 4) for k in ("ms_generate", "ms_extend", "ms_shade", "ms_sort", "ms_shadow", "ms_fused", "ms_path", "ms_accumulate", "ms_total")},
         "device": rd.Platform.device_name(),
     }
     if also:

@@ -172,7 +172,7 @@ typedef struct rdx_trace_stats {
     float    ms_path;                                  /* whole-path launches ("pipeline" 1) */
     uint32_t launches_extend, launches_shadow;
     uint32_t groups;                                   /* sample groups the last chunk was traced in (option "groups") */
-    uint32_t reserved;
+    float    ms_sort;                                  /* per-bounce ray sort launches (option "sort") */
 } rdx_trace_stats;
 int         rdx_get_trace_stats(rdx_trace_stats* out);
 /* per-bounce visit counters of the last frame traced with "count_visits": out[8*d + 4*c + k], c = 0
@@ -188,7 +188,9 @@ int         rdx_set_profiling(int on);
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 3 = wave-
  * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
  * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
- * cross-checks), "textures" (0 (default) / 1.  The live reference shader has every texture read commented out (`uint4 tex =
+ * cross-checks), "sort" (-1 (default) = automatic, 1 / 0: per-bounce ray sort -- the survivors of a bounce are handed to the
+ * traversal launch in (direction octant, Morton cell of the origin) order, by an index permutation from a counting sort; the
+ * path streams are not moved and no result depends on it), "textures" (0 (default) / 1.  The live reference shader has every texture read commented out (`uint4 tex =
  * 0.0f;//read_imageui(...)`, samples/shader.cl:379,411,421,445), so a material with a texture index renders with texel 0; that
  * is what 0 reproduces, bit for bit.  1 performs the commented-out read -- coord (uv.x, 1 - uv.y, texIdx), as the reference's
  * older shader2.cl:255-265 does live -- from the image array in slot 11 through the sampler in slot 12), "cull" (pool kernel: -1 (default) = automatic, 1 / 0 = on / off: closest-hit rays skip subtrees the ray enters

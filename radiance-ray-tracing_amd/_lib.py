@@ -23,7 +23,7 @@ class rdx_trace_stats(C.Structure):
                 ("ms_total", C.c_float), ("ms_generate", C.c_float), ("ms_extend", C.c_float),
                 ("ms_shade", C.c_float), ("ms_shadow", C.c_float), ("ms_accumulate", C.c_float),
                 ("ms_fused", C.c_float), ("ms_path", C.c_float), ("launches_extend", C.c_uint32), ("launches_shadow", C.c_uint32),
-                ("groups", C.c_uint32), ("reserved", C.c_uint32)]
+                ("groups", C.c_uint32), ("ms_sort", C.c_float)]
 
 
 class rdx_material(C.Structure):

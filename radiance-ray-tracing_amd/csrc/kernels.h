@@ -78,7 +78,27 @@ struct PathStreams {
     float4* colLit;    // colour if the light is visible
     float4* colSh;     // colour if it is occluded
     float4* sampleColor; // [samples_in_chunk][pixels] final per-sample radiance
+    // per-bounce ray sort (option "sort"): the order in which the persistent traversal launch HANDS OUT the rays of this
+    // bounce -- work item i is path permS[i] (shadow query) / permE[i] (next-bounce ray).  Null = identity.  Nothing is moved:
+    // the streams stay in compaction order, only the waves' ray assignment follows the sort.
+    const uint32_t* permS;
+    const uint32_t* permE;
 };
+
+// per-bounce ray sort: counting sort of the m survivors of shade(d) by (direction octant, Morton code of the origin's cell in
+// a 16^3 grid over the scene box) into two permutations, one for the shadow queries (key: origin cell only, the direction is
+// the light's) and one for the next bounce's rays.  Coherent rays crowd into few bins and same-address atomics serialise in
+// the L2, so every bin has SORT_REP replicas (a block uses replica blockIdx % SORT_REP) laid out bin-major: one linear
+// exclusive scan over bins x replicas then gives every (bin, replica) its output range.
+// bins: SORT_WORDS words, zeroed by the call; perm: 2 x nMax words.
+constexpr uint32_t SORT_BINS = 1u << 15;             // 3 octant bits + 12 Morton bits
+constexpr uint32_t SORT_REP = 32u;
+constexpr uint32_t SORT_TILE = 4096u;                // counters per scan tile
+constexpr uint32_t SORT_TILES = 2u * SORT_BINS * SORT_REP / SORT_TILE;                  // both arrays
+constexpr uint32_t SORT_WORDS = 2u * SORT_BINS * SORT_REP + SORT_TILES;                 // counters + tile sums
+struct SortBox { float lo[3]; float inv[3]; };      // cell = (p - lo) * inv, clamped to 0..15
+void launch_ray_sort(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* bins,
+                     uint32_t* permS, uint32_t* permE);
 
 // LDS words one wave of the cooperative / pool engine needs for the given stack needs (traverse_coop.h, traverse_pool.h)
 uint32_t coop_lds_words(uint32_t coopNeed);

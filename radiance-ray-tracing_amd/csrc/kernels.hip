@@ -608,6 +608,122 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-bounce ray sort (option "sort"): see kernels.h
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread4(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }
+__device__ __forceinline__ uint32_t sort_cell(const SortBox& B, float x, float y, float z)
+{
+    const uint32_t cx = (uint32_t)fminf(fmaxf((x - B.lo[0]) * B.inv[0], 0.0f), 15.0f);
+    const uint32_t cy = (uint32_t)fminf(fmaxf((y - B.lo[1]) * B.inv[1], 0.0f), 15.0f);
+    const uint32_t cz = (uint32_t)fminf(fmaxf((z - B.lo[2]) * B.inv[2], 0.0f), 15.0f);
+    return spread4(cx) | (spread4(cy) << 1) | (spread4(cz) << 2);            // 12-bit Morton code
+}
+__device__ __forceinline__ void sort_keys(const PathStreams& ps, const SortBox& B, uint32_t j, uint32_t& kS, uint32_t& kE)
+{
+    const float4 so = ps.shO[j], ro = ps.nRayO[j], rd = ps.nRayD[j];
+    kS = sort_cell(B, so.x, so.y, so.z);
+    kE = (((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) << 12) | sort_cell(B, ro.x, ro.y, ro.z);
+}
+// bins[key] += 1 for every active lane, returning the old value (the lane's slot) -- with the lanes of a wave that share a
+// key combined into ONE atomic (up to 8 distinct keys are peeled off this way, the rest go singly).  Coherent rays crowd
+// into few bins: without the aggregation a bounce's 2 M atomics on a few dozen hot words took 2-4 ms.
+__device__ __forceinline__ uint32_t sort_bin_add(uint32_t* __restrict__ bins, uint32_t key, bool active)
+{
+    const uint32_t lane = __lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long todo = __ballot(active);
+    uint32_t leader = lane, rank = 0, cnt = 1;             // a lane not peeled off below is a group of its own
+    for (int it = 0; it < 8 && todo != 0ull; ++it) {
+        const int l0 = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = __shfl(key, l0);
+        const unsigned long long same = __ballot(active && key == k0) & todo;
+        if ((same >> lane) & 1ull) { leader = (uint32_t)l0; rank = (uint32_t)__popcll(same & lt); cnt = (uint32_t)__popcll(same); }
+        todo &= ~same;
+    }
+    uint32_t base = 0;
+    if (active && leader == lane) base = atomicAdd(&bins[key], cnt);       // every group's atomic is in flight at once
+    return __shfl(base, leader) + rank;
+}
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_sort_hist(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32_t* __restrict__ bins)
+{
+    // grid-stride over the m survivors (m lives on the device; the grid is sized for a resident set, not for the bound)
+    const uint32_t m = *mPtr, r = blockIdx.x % SORT_REP;
+    for (uint32_t base = blockIdx.x * RDX_BLOCK; base < m; base += gridDim.x * RDX_BLOCK) {
+        const uint32_t j = base + threadIdx.x;
+        const bool active = j < m;
+        uint32_t kS = 0, kE = 0;
+        if (active) sort_keys(ps, B, j, kS, kE);
+        sort_bin_add(bins, kS * SORT_REP + r, active);
+        sort_bin_add(bins + SORT_BINS * SORT_REP, kE * SORT_REP + r, active);
+    }
+}
+// exclusive scan inside tiles of SORT_TILE counters (256 threads x 16 consecutive counters), tile totals to sums[tile]
+__global__ void __launch_bounds__(256)
+k_sort_scan_tiles(uint32_t* __restrict__ bins, uint32_t* __restrict__ sums)
+{
+    static_assert(SORT_TILE == 256u * 16u, "tile shape");
+    __shared__ uint32_t part[256];
+    uint4* p = reinterpret_cast<uint4*>(bins + (size_t)blockIdx.x * SORT_TILE + threadIdx.x * 16u);
+    uint4 v[4];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = p[k]; sum += v[k].x + v[k].y + v[k].z + v[k].w; }
+    const uint32_t t = threadIdx.x;
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
+        const uint32_t x = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint4 o;
+        o.x = run; run += v[k].x; o.y = run; run += v[k].y; o.z = run; run += v[k].z; o.w = run; run += v[k].w;
+        p[k] = o;
+    }
+    if (t == 255u) sums[blockIdx.x] = part[255];
+}
+// exclusive scan of the tile totals of each of the two arrays (one block per array, SORT_TILES / 2 <= 1024 tiles)
+__global__ void __launch_bounds__(1024)
+k_sort_scan_sums(uint32_t* __restrict__ sums)
+{
+    static_assert(SORT_TILES / 2u <= 1024u, "one thread per tile");
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, n = SORT_TILES / 2u;
+    uint32_t* s = sums + blockIdx.x * n;
+    const uint32_t v = t < n ? s[t] : 0u;
+    part[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t x = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    if (t < n) s[t] = part[t] - v;
+}
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_sort_scatter(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32_t* __restrict__ bins, const uint32_t* __restrict__ sums,
+               uint32_t* __restrict__ permS, uint32_t* __restrict__ permE)
+{
+    const uint32_t m = *mPtr, r = blockIdx.x % SORT_REP;
+    for (uint32_t base = blockIdx.x * RDX_BLOCK; base < m; base += gridDim.x * RDX_BLOCK) {
+        const uint32_t j = base + threadIdx.x;
+        const bool active = j < m;
+        uint32_t kS = 0, kE = 0;
+        if (active) sort_keys(ps, B, j, kS, kE);
+        const uint32_t cS = kS * SORT_REP + r, cE = SORT_BINS * SORT_REP + kE * SORT_REP + r;
+        const uint32_t pS = sort_bin_add(bins, cS, active);          // (the order inside a bin is arbitrary: no result depends on it)
+        const uint32_t pE = sort_bin_add(bins, cE, active);
+        if (active) { permS[pS + sums[cS / SORT_TILE]] = j; permE[pE + sums[cE / SORT_TILE]] = j; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // shadow: any-hit walk of the deferred shadow query, then hand over to the next bounce
 // ---------------------------------------------------------------------------------------------
 template <bool COUNT>
@@ -775,15 +891,17 @@ __device__ __forceinline__ void write_hit_record(const AccelView& A, const Trace
 struct ExtendPolicy {
     AccelView A; PathStreams ps;
     RDX_SINGLE_RAY_POLICY
-    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
+    __device__ __forceinline__ bool load(uint32_t w, f3& o, f3& d, bool& anyHit) const
     {
+        const uint32_t i = ps.permE ? ps.permE[w] : w;          // work item w = path i (per-bounce ray sort)
         const float4 ro = ps.rayO[i], rd = ps.rayD[i];
         o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
         anyHit = false;
         return true;
     }
-    __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const
+    __device__ __forceinline__ void store(uint32_t w, const Best& b, f3, f3) const
     {
+        const uint32_t i = ps.permE ? ps.permE[w] : w;
         ps.hitA[i] = make_float4(b.t, b.b1, b.b2, b.hit ? u2f(A.tris[b.slot].primID) : 0.0f);
         ps.hitInst[i] = b.hit ? b.inst : RDX_MISS;
     }
@@ -792,15 +910,17 @@ struct ExtendPolicy {
 struct ShadowPolicy {
     AccelView A; PathStreams ps; f3 Ldir; uint32_t lastBounce, nPixels, sampleBase;
     RDX_SINGLE_RAY_POLICY
-    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
+    __device__ __forceinline__ bool load(uint32_t w, f3& o, f3& d, bool& anyHit) const
     {
+        const uint32_t i = ps.permS ? ps.permS[w] : w;
         const float4 so = ps.shO[i];
         o = mk3(so.x, so.y, so.z); d = Ldir;
         anyHit = true;
         return so.w != 0.0f;                    // the closest-hit shader asked for a shadow query
     }
-    __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const
+    __device__ __forceinline__ void store(uint32_t w, const Best& b, f3, f3) const
     {
+        const uint32_t i = ps.permS ? ps.permS[w] : w;
         // hit -> closest-hit row 2 `shadow` sets payload.hit; miss -> row 4 `shadowMiss` clears it
         bool occluded = false;
         if (ps.shO[i].w != 0.0f) {
@@ -1231,6 +1351,19 @@ void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
     if (!nMax) return;
     hipLaunchKernelGGL(k_shade, dim3(blocks_for(nMax, RDX_SHADE_BLOCK)), dim3(RDX_SHADE_BLOCK), 0, st, av, sc, ps, nPtr, nOut, depth,
                        maxDepth, nPixels, sampleBase);
+}
+
+void launch_ray_sort(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* bins,
+                     uint32_t* permS, uint32_t* permE)
+{
+    if (!nMax) return;
+    uint32_t* sums = bins + 2u * SORT_BINS * SORT_REP;
+    (void)hipMemsetAsync(bins, 0, (size_t)SORT_WORDS * sizeof(uint32_t), st);
+    const uint32_t grid = std::min<uint32_t>(blocks_for(nMax, RDX_BLOCK), 256u * 8u);
+    hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(RDX_BLOCK), 0, st, ps, mPtr, box, bins);
+    hipLaunchKernelGGL(k_sort_scan_tiles, dim3(SORT_TILES), dim3(256), 0, st, bins, sums);
+    hipLaunchKernelGGL(k_sort_scan_sums, dim3(2), dim3(1024), 0, st, sums);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(RDX_BLOCK), 0, st, ps, mPtr, box, bins, sums, permS, permE);
 }
 
 void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,

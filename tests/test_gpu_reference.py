@@ -109,9 +109,10 @@ def test_product_matches_reference_goldens(mods, name):
     got = rd.MaterialBatch(hits, G["mat_dir"], np.arange(n, dtype=np.uint32), frames, depths)
     lit, occ = _check_material(s, hits, ref_pay, got)
     assert lit > 100
-    # two progressive frames: imageScratch and RGBA8 bit for bit, with the culled and with the exhaustive walk
+    # two progressive frames: imageScratch and RGBA8 bit for bit, with the culled and with the exhaustive walk (the latter
+    # also with the per-bounce ray sort, which only changes the order rays are handed to the traversal launches)
     for cull in (1, 0):
-        rd.SetOption("cull", cull)
+        rd.SetOption("cull", cull); rd.SetOption("sort", 1 - cull)
         try:
             dev.set_rtprop(totalSamples=0); dev.clear_scratch()
             for f in range(2):
@@ -119,7 +120,7 @@ def test_product_matches_reference_goldens(mods, name):
                 assert np.array_equal(_bits(dev.read_scratch().reshape(-1)), _bits(G["scratch%d" % f])), (cull, f)
                 assert np.array_equal(img.reshape(-1), G["image%d" % f]), (cull, f)
         finally:
-            rd.SetOption("cull", -1)
+            rd.SetOption("cull", -1); rd.SetOption("sort", -1)
     if name == "c1":
         dev2 = scenes.DeviceScene(gc.small_scene(scenes, name, fstop=2.8))
         lo, ld = rd.GenerateBatch(px, G["gen_rnd"])
@@ -161,11 +162,11 @@ def test_full_size_frames_identical_to_reference(mods, ref, cfg, cull):
     dev = scenes.DeviceScene(s)
     blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
     rs = rg.RefScene(ref, s, blob)
-    rd.SetOption("cull", cull)
+    rd.SetOption("cull", cull); rd.SetOption("sort", cull)       # (sorted hand-out together with the culled walk)
     try:
         t = _frames_identical(rd, dev, rs, frames=2)
     finally:
-        rd.SetOption("cull", -1)
+        rd.SetOption("cull", -1); rd.SetOption("sort", -1)
     print("%s: reference kernel %.0f ms, product %.1f ms per frame" % (cfg, t[0][0], t[0][1]))
 
 
