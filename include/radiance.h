@@ -14,7 +14,7 @@
 #include "clcontext.h"
 
 #ifndef SHADER_LIB_PATH
-#define SHADER_LIB_PATH ""      // the reference passes -I<this> to its OpenCL JIT; unused here
+#define SHADER_LIB_PATH ""      // the reference passes -I<this> to its OpenCL JIT; so does the run-time compilation of user shader programs
 #endif
 
 namespace RD
@@ -160,6 +160,7 @@ inline PipelineLayout CreatePipelineLayout(std::vector<DescriptorType> descripto
 inline ShaderModule CreateShaderModule(Platform*, char* code, unsigned int size, char* name)
 {
     printf("build program and get raygen kernel\n");
+    if (SHADER_LIB_PATH[0]) rdx_shader_include_path(SHADER_LIB_PATH);      // the reference's clBuildProgram("-g -I" SHADER_LIB_PATH)
     return detail::need(rdx_shader_module_create(code, size, name), "CreateShaderModule");
 }
 inline ShaderModule CreateShaderModule(Platform* p, char* code, unsigned int size, const char* name) { return CreateShaderModule(p, code, size, const_cast<char*>(name)); }

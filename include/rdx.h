@@ -128,11 +128,17 @@ void        rdx_obj_free(rdx_obj_scene* scene);
 
 /* ---- pipeline: replaces CreateShaderModule / BindPipeline / BindDescriptorSet / TraceRays
  *      (radiance.h:130-144, radiance.cpp:152-179,226-267).
- *      `code` is the user's shader text; the stage functions named in samples/sbt.json
- *      (raygen, material, shadow, anyShadow, environment, shadowMiss) are resolved against the
- *      hand-written HIP stages compiled into this library (tools/genSBT.py emits the dispatch).
- *      A shader that names no `raygen` kernel fails here, as clCreateKernel("raygen") would. */
+ *      `code` is the user's shader text.  The reference's stock program (samples/shader.cl: the stage functions named in
+ *      samples/sbt.json -- raygen, material, shadow, anyShadow, environment, shadowMiss) is recognised and served by the
+ *      hand-written HIP wavefront pipeline of this library (tools/genSBT.py emits the dispatch); so is a placeholder whose
+ *      `raygen` takes no parameters.  ANY OTHER program is compiled at run time by ROCm's OpenCL C compiler for the GPU in
+ *      use and launched as a megakernel, one work-item per pixel, parameters bound by position (slots 11 / 12 as null
+ *      descriptors) -- as the reference's clBuildProgram + clEnqueueNDRangeKernel would, csrc/user_shader.cpp.  A text that
+ *      names no `raygen` kernel, or does not compile (the build log is in rdx_last_error), fails here. */
 rdx_shader  rdx_shader_module_create(const char* code, uint32_t size, const char* name);
+/* -I directory for `#include "radiance.cl"` etc. in user shader programs: the reference bakes SHADER_LIB_PATH into its
+ * binary (radiance.h:7, radiance.cpp:165-167); here it is a run-time setting (the RD:: facade passes SHADER_LIB_PATH). */
+int         rdx_shader_include_path(const char* path);
 int         rdx_bind_pipeline(rdx_shader raygen_module);
 /* handles[i] binds to parameter i of the raygen kernel (samples/shader.cl:175-190):
  * 0 RTProp, 1 imageScratch, 2 image, 3 camData, 4 scene, 5 meshInfo, 6 vertex, 7 index, 8 uv,
@@ -188,7 +194,8 @@ int         rdx_set_profiling(int on);
  * triangle visits; slower, for the roofline byte model), "kernel" (traversal kernel: 3 = wave-
  * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
  * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
- * cross-checks), "sort" (-1 (default) = automatic, 1 / 0: per-bounce ray sort -- the survivors of a bounce are handed to the
+ * cross-checks), "user_shader_local_size" (work-group size of a user shader program's launch, default 64; the reference
+ * launches with 1, radiance.cpp:250-259 -- results do not depend on it), "sort" (-1 (default) = automatic, 1 / 0: per-bounce ray sort -- the survivors of a bounce are handed to the
  * traversal launch in (direction octant, Morton cell of the origin) order, by an index permutation from a counting sort; the
  * path streams are not moved and no result depends on it), "textures" (0 (default) / 1.  The live reference shader has every texture read commented out (`uint4 tex =
  * 0.0f;//read_imageui(...)`, samples/shader.cl:379,411,421,445), so a material with a texture index renders with texel 0; that

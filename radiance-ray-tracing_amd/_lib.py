@@ -85,6 +85,7 @@ SIGNATURES = {
     "rdx_tlas_to_file": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rdx_tlas_from_file": (C.c_void_p, [C.c_char_p]),
     "rdx_shader_module_create": (C.c_void_p, [C.c_char_p, C.c_uint32, C.c_char_p]),
+    "rdx_shader_include_path": (C.c_int, [C.c_char_p]),
     "rdx_bind_pipeline": (C.c_int, [C.c_void_p]),
     "rdx_bind_descriptor_set": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32]),
     "rdx_trace_rays": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -15,8 +15,8 @@ LIB = os.path.join(HERE, "librdx.so")
 EXTRA = os.environ.get("RDX_DEFINES", "").split()
 if os.environ.get("RDX_LIB_NAME"):
     LIB = os.path.join(HERE, os.environ["RDX_LIB_NAME"])
-SOURCES = ["kernels.hip", "rdx_runtime.cpp", "bvh_build.cpp", "scene_obj.cpp"]
-HEADERS = ["kernels.h", "stages.h", "device_math.h", "rdx_types.h", "bvh_build.h", "sbt_generated.h", "traverse_coop.h", "traverse_pool.h",
+SOURCES = ["kernels.hip", "rdx_runtime.cpp", "bvh_build.cpp", "scene_obj.cpp", "user_shader.cpp"]
+HEADERS = ["kernels.h", "stages.h", "device_math.h", "rdx_types.h", "bvh_build.h", "sbt_generated.h", "traverse_coop.h", "traverse_pool.h", "user_shader.h",
            os.path.join("..", "..", "include", "rdx.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

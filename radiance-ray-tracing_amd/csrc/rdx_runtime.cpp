@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include "device_math.h"
 #include "kernels.h"
 #include "rdx_types.h"
+#include "user_shader.h"
 
 using namespace rdx;
 
@@ -85,7 +87,7 @@ struct rdx_buffer_s {
 };
 struct rdx_sampler_s { uint32_t addressing = 0, filter = 0; };
 struct rdx_blas_s { std::unique_ptr<Blas> blas; };
-struct rdx_shader_s { std::string name; bool hasRaygen = false; };
+struct rdx_shader_s { std::string name; bool hasRaygen = false; UserProgram* program = nullptr; };   // program != null: a user's own raygen, compiled at run time
 
 namespace {
 
@@ -139,6 +141,8 @@ struct Context {
     int cull = -1;                          // pool engine: culled walk (option "cull"): 1 on, 0 off, -1 = on for scenes of >= 16 k inner nodes
     int textures = 0;                       // option "textures": 1 = the stock shader samples the bound image array
     std::vector<std::unique_ptr<rdx_sampler_s>> samplers;
+    std::string shaderInclude;              // -I for user shader programs (rdx_shader_include_path; the reference's SHADER_LIB_PATH)
+    int userLocalSize = 64;                 // option "user_shader_local_size": work-group size of a user program's launch (the reference uses 1)
     int sortRays = -1;                      // option "sort": per-bounce ray sort: 1 on, 0 off, -1 automatic
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
@@ -766,6 +770,7 @@ extern "C" int rdx_shutdown(void)
     HIP_IGN(hipSetDevice(g_phys[0]));
     HIP_IGN(hipStreamSynchronize(g.stream));
     for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
+    for (auto& sh : g.shaders) if (sh->program) release_user_shader(sh->program);
     g.buffers.clear(); g.blases.clear(); g.shaders.clear();
     release_device_state();
     g = Context{};
@@ -1102,21 +1107,78 @@ static bool has_identifier(const std::string& text, const char* name)
     return false;
 }
 
+// text with comments removed (so that a commented-out parameter list or identifier does not count)
+static std::string strip_comments(const std::string& t)
+{
+    std::string o;
+    o.reserve(t.size());
+    for (size_t i = 0; i < t.size();) {
+        if (t.compare(i, 2, "//") == 0) { while (i < t.size() && t[i] != '\n') ++i; }
+        else if (t.compare(i, 2, "/*") == 0) { const size_t e = t.find("*/", i + 2); i = e == std::string::npos ? t.size() : e + 2; o.push_back(' '); }
+        else o.push_back(t[i++]);
+    }
+    return o;
+}
+
+// does `raygen` take parameters?  (-1: no raygen( found)
+static int raygen_has_parameters(const std::string& t)
+{
+    for (size_t pos = t.find("raygen"); pos != std::string::npos; pos = t.find("raygen", pos + 1)) {
+        size_t i = pos + 6;
+        while (i < t.size() && std::isspace((unsigned char)t[i])) ++i;
+        if (i >= t.size() || t[i] != '(') continue;
+        const size_t e = t.find(')', i);
+        if (e == std::string::npos) return -1;
+        std::string inner = t.substr(i + 1, e - i - 1);
+        inner.erase(std::remove_if(inner.begin(), inner.end(), [](unsigned char c) { return std::isspace(c); }), inner.end());
+        return (inner.empty() || inner == "void") ? 0 : 1;
+    }
+    return -1;
+}
+
+static uint64_t fnv1a64_nows(const std::string& t)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char c : t) { if (std::isspace(c)) continue; h ^= c; h *= 0x100000001b3ull; }
+    return h;
+}
+
+extern "C" int rdx_shader_include_path(const char* path)
+{
+    g0.shaderInclude = path ? path : "";
+    return 0;
+}
+
 extern "C" rdx_shader rdx_shader_module_create(const char* code, uint32_t size, const char* name)
 {
     if (!g.initialized) { fail("rdx_init has not been called"); return nullptr; }
     if (!code) { fail("CreateShaderModule: null shader text"); return nullptr; }
     const std::string text(code, size);
-    // The reference JIT-compiles `code` and takes the kernel named "raygen" (radiance.cpp:177); the
-    // stage functions it dispatches to are those of samples/sbt.json, which this library ships as
-    // hand-written HIP stages.  Accept the text if it declares that entry point.
-    if (!has_identifier(text, "raygen")) {
+    // The reference JIT-compiles `code` and takes the kernel named "raygen" (radiance.cpp:152-179).  Three cases here:
+    //  1. the text IS the reference's stock program (samples/shader.cl, recognised by a hash of its non-blank characters): its
+    //     stage functions are the ones of samples/sbt.json that this library ships as hand-written HIP -> wavefront pipeline;
+    //  2. `raygen` declared without parameters: a placeholder that asks for the stock pipeline (nothing could be bound to it);
+    //  3. any other program: compiled at run time by ROCm's OpenCL C compiler and run as the megakernel it is (user_shader.cpp).
+    const std::string bare = strip_comments(text);
+    if (!has_identifier(bare, "raygen")) {
         fail("CreateShaderModule: shader text has no `raygen` kernel (clCreateKernel(\"raygen\") would fail)");
         return nullptr;
     }
     auto s = std::make_unique<rdx_shader_s>();
     s->name = name ? name : "";
     s->hasRaygen = true;
+    constexpr uint64_t kStockShaderHash = 0xc0cc932e07087140ull;      // FNV-1a-64 of samples/shader.cl without white space (16 983 characters)
+    const bool stock = fnv1a64_nows(text) == kStockShaderHash || raygen_has_parameters(bare) == 0;
+    if (!stock) {
+        if (g_ndev > 1) { fail("CreateShaderModule: user shader programs are not supported in multi-device mode"); return nullptr; }
+        hipDeviceProp_t prop;
+        HIP_OKP(hipGetDeviceProperties(&prop, g0.device));
+        std::string arch = prop.gcnArchName;
+        arch = arch.substr(0, arch.find(':'));
+        std::string err;
+        s->program = compile_user_shader(text, g0.shaderInclude, arch, err);
+        if (!s->program) { fail("%s", err.c_str()); return nullptr; }
+    }
     g.shaders.push_back(std::move(s));
     return g.shaders.back().get();
 }
@@ -1213,6 +1275,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "overlap")) { if (value < 0 || value > 1) return fail("overlap must be 0 or 1"); g.overlap = (int)value; return 0; }
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
+    if (!strcmp(name, "user_shader_local_size")) { if (value < 1 || value > 1024) return fail("user_shader_local_size must be 1..1024"); g.userLocalSize = (int)value; return 0; }
     if (!strcmp(name, "sort")) { g.sortRays = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "textures")) { g.textures = value != 0; return 0; }
     if (!strcmp(name, "cull")) { g.cull = value < 0 ? -1 : (value != 0); return 0; }
@@ -1254,6 +1317,29 @@ static int trace_rays_device(uint32_t width, uint32_t height)
     auto* bTlas = static_cast<rdx_buffer_s*>(g.slots[13]);
     const uint64_t nPix = (uint64_t)width * height;
     if (nPix == 0) return 0;
+    if (g.pipeline->program) {
+        // a user's own raygen program: the megakernel, one work-item per pixel, bound by position like clSetKernelArg
+        // (radiance.cpp:231-259); slots 11 / 12 (texture array, sampler) are passed as null descriptors
+        if (nPix > 0xffffffffull) return fail("TraceRays: too many pixels");
+        void* ptrs[12];
+        const int slotOf[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13};
+        for (int i = 0; i < 12; ++i) {
+            void* h = g.slots[slotOf[i]];
+            if (!h || !known_buffer(h)) return fail("descriptor slot %d is not a buffer", slotOf[i]);
+            ptrs[i] = dp(static_cast<rdx_buffer_s*>(h));
+        }
+        std::memset(&g.stats, 0, sizeof g.stats);
+        g.stats.pixels = nPix;
+        HIP_OK(hipEventRecord(g.evA, g.stream));
+        std::string err;
+        if (launch_user_shader(g.pipeline->program, g.stream, ptrs, (uint32_t)nPix, (uint32_t)g.userLocalSize, err)) return fail("%s", err.c_str());
+        HIP_OK(hipEventRecord(g.evB, g.stream));
+        HIP_OK(hipStreamSynchronize(g.stream));
+        HIP_OK(hipEventElapsedTime(&g.stats.ms_total, g.evA, g.evB));
+        // the program wrote imageScratch / image itself: host mirrors of nothing are affected (only RTProp / camera are mirrored,
+        // and a raygen that wrote them would be outside the reference's host contract, sample1.cpp:480-490)
+        return 0;
+    }
     if (nPix > 0x7fffffffull) return fail("TraceRays: %llu pixels exceed the 31-bit pixel index", (unsigned long long)nPix);
     if (bRT->size < sizeof(RayTraceProperties) || bCam->size < sizeof(PhysicalCamera)) return fail("TraceRays: RTProp / camera buffer too small");
     if (bScratch->size < nPix * 16) return fail("TraceRays: imageScratch holds %zu bytes, %llu needed", bScratch->size, (unsigned long long)nPix * 16);

@@ -1,0 +1,170 @@
+// user_shader.cpp -- run-time compilation of a user's OpenCL C `raygen` program.
+//
+// The reference hands the text given to RD::CreateShaderModule to the OpenCL driver's JIT -- clCreateProgramWithSource +
+// clBuildProgram("-g -I" SHADER_LIB_PATH) + clCreateKernel("raygen"), radiance/src/radiance.cpp:152-179 -- so ANY OpenCL C
+// program with a `raygen` kernel of the 14-parameter binding contract (samples/shader.cl:175-190) runs.  The stock program
+// (the stage functions of samples/sbt.json) is served by the hand-written wavefront pipeline of this library; every OTHER
+// program is compiled here, for the GPU in use, by ROCm's own OpenCL C compiler (clang, -x cl, the ROCm OpenCL builtin
+// library) and launched as what it is: a megakernel, one work-item per pixel.  It is a compatibility path -- a user who
+// edits a shader gets the edited shader, at megakernel speed -- not the fast path.
+//
+// Mechanics.  The HIP runtime cannot launch kernels that take `image2d_array_t` / `sampler_t` parameters (its host side
+// dereferences image objects that do not exist), and OpenCL C cannot spell a null image.  So the user's text gets a small
+// function appended that forwards to `raygen` and keeps the two opaque parameters, a second translation unit declares that
+// function with the two parameters as `__constant void*` -- on amdgcn both ARE pointers to constant-address-space descriptors --
+// and holds the __kernel entry point that passes null for them; the two units are joined with llvm-link.  User programs
+// therefore cannot sample textures yet (the live reference shader does not either, shader.cl:379-445).
+// `#include "radiance.cl"` etc. resolve through the include path given to rdx_shader_include_path (the reference bakes
+// SHADER_LIB_PATH into its binary, radiance.h:7): the user's copy of the reference's shader library.
+#include "user_shader.h"
+
+#include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <vector>
+
+extern char** environ;
+
+namespace rdx {
+
+namespace {
+
+const char* kForwarder =
+    "\n\n/* ---- appended by the runtime: forwards to the program's raygen kernel (see user_shader.cpp) ---- */\n"
+    "void rdx_user_raygen(__global void* a0, __global void* a1, __global void* a2, __global void* a3, __global void* a4,\n"
+    "                     __global void* a5, __global void* a6, __global void* a7, __global void* a8, __global void* a9,\n"
+    "                     __global void* a10, __global void* a13, uint npixels, image2d_array_t img, sampler_t smp)\n"
+    "{\n"
+    "    if (get_global_id(0) >= npixels) return;\n"
+    "    raygen(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, img, smp, a13);\n"
+    "}\n";
+
+const char* kEntry =
+    "typedef __global void* gp;\n"
+    "typedef __constant void* op;\n"
+    "void rdx_user_raygen(gp, gp, gp, gp, gp, gp, gp, gp, gp, gp, gp, gp, uint, op, op);\n"
+    "__kernel void rdx_user_entry(gp a0, gp a1, gp a2, gp a3, gp a4, gp a5, gp a6, gp a7, gp a8, gp a9, gp a10, gp a13, uint npixels)\n"
+    "{\n"
+    "    rdx_user_raygen(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a13, npixels, 0, 0);\n"
+    "}\n";
+
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+std::string slurp(const std::string& p)
+{
+    std::ifstream f(p);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+// run argv[0] with stdout + stderr appended to `log`; 0 on success
+int run(const std::vector<std::string>& argv, const std::string& log)
+{
+    std::vector<char*> av;
+    for (auto& a : argv) av.push_back(const_cast<char*>(a.c_str()));
+    av.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0600);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) return -1;
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0) return -1;
+    return (WIFEXITED(status) && WEXITSTATUS(status) == 0) ? 0 : -1;
+}
+
+} // namespace
+
+UserProgram* compile_user_shader(const std::string& text, const std::string& includePath, const std::string& arch, std::string& err)
+{
+    const char* envClang = std::getenv("RDX_CLANG");
+    const std::string clang = envClang ? envClang : "/opt/rocm/lib/llvm/bin/clang";
+    const std::string link = clang.substr(0, clang.find_last_of('/') + 1) + "llvm-link";
+    const char* envRocm = std::getenv("ROCM_PATH");
+    const std::string rocm = envRocm ? envRocm : "/opt/rocm";
+    if (!exists(clang) || !exists(link)) {
+        err = "user shader: the OpenCL C compiler is not installed (" + clang + ", llvm-link; set RDX_CLANG)";
+        return nullptr;
+    }
+    char tmpl[] = "/tmp/rdx_jit_XXXXXX";
+    if (!mkdtemp(tmpl)) { err = "user shader: cannot create a temporary directory"; return nullptr; }
+    const std::string dir = tmpl, log = dir + "/build.log";
+    { std::ofstream f(dir + "/user.cl"); f << text << kForwarder; }
+    { std::ofstream f(dir + "/entry.cl"); f << kEntry; }
+    std::vector<std::string> common = {clang, "-x", "cl", "-cl-std=CL1.2", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + arch, "-Xclang",
+                                       "-finclude-default-header", "--rocm-path=" + rocm, "-O3"};
+    // extra options, e.g. RDX_JIT_FLAGS="-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt" (the contract of the stock pipeline)
+    if (const char* extra = std::getenv("RDX_JIT_FLAGS")) {
+        std::stringstream ss(extra);
+        std::string tok;
+        while (ss >> tok) common.push_back(tok);
+    }
+    auto cleanup = [&]() { if (!std::getenv("RDX_JIT_KEEP")) { std::string cmd = "rm -rf '" + dir + "'"; (void)!system(cmd.c_str()); } };
+    std::vector<std::string> a = common;
+    if (!includePath.empty()) a.push_back("-I" + includePath);
+    // the printf lowering introduces a library call after the first link of the builtin bitcode
+    for (const char* s : {"-Xclang", "-mlink-builtin-bitcode-postopt", "-emit-llvm", "-c"}) a.push_back(s);
+    a.push_back(dir + "/user.cl"); a.push_back("-o"); a.push_back(dir + "/user.bc");
+    std::vector<std::string> b = common;
+    for (const char* s : {"-w", "-emit-llvm", "-c"}) b.push_back(s);
+    b.push_back(dir + "/entry.cl"); b.push_back("-o"); b.push_back(dir + "/entry.bc");
+    const std::vector<std::string> c = {link, dir + "/user.bc", dir + "/entry.bc", "-o", dir + "/all.bc"};
+    const std::vector<std::string> d = {clang, "-target", "amdgcn-amd-amdhsa", "-mcpu=" + arch, "-O3", dir + "/all.bc", "-o", dir + "/user.co"};
+    if (run(a, log) || run(b, log) || run(c, log) || run(d, log)) {
+        std::string l = slurp(log);
+        if (l.size() > 10000) l.resize(10000);                 // the reference prints at most 10 000 bytes of build log (radiance.cpp:170)
+        err = "user shader: compilation failed\n" + l;
+        cleanup();
+        return nullptr;
+    }
+    auto* p = new UserProgram();
+    hipError_t e = hipModuleLoad(&p->module, (dir + "/user.co").c_str());
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->entry, p->module, "rdx_user_entry");
+    if (e != hipSuccess) {
+        err = std::string("user shader: loading the compiled program failed: ") + hipGetErrorString(e);
+        delete p;
+        cleanup();
+        return nullptr;
+    }
+    p->log = slurp(log);
+    cleanup();
+    return p;
+}
+
+int launch_user_shader(UserProgram* p, hipStream_t st, void* const ptrs[12], uint32_t npixels, uint32_t localSize, std::string& err)
+{
+    struct Args { void* p[12]; uint32_t n; uint32_t pad; } args;
+    for (int i = 0; i < 12; ++i) args.p[i] = ptrs[i];
+    args.n = npixels; args.pad = 0;
+    size_t size = sizeof(void*) * 12 + sizeof(uint32_t);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    if (localSize == 0) localSize = 64;
+    const uint32_t grid = (npixels + localSize - 1) / localSize;
+    if (grid == 0) return 0;
+    hipError_t e = hipModuleLaunchKernel(p->entry, grid, 1, 1, localSize, 1, 1, 0, st, nullptr, extra);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { err = std::string("user shader: launch failed: ") + hipGetErrorString(e); return -1; }
+    return 0;
+}
+
+void release_user_shader(UserProgram* p)
+{
+    if (!p) return;
+    if (p->module) (void)hipModuleUnload(p->module);
+    delete p;
+}
+
+} // namespace rdx

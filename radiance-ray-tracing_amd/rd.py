@@ -315,6 +315,11 @@ def CreateShaderModule(platform, code, size, name):
     return h
 
 
+def SetShaderIncludePath(path):
+    """-I directory for user shader programs (the reference's SHADER_LIB_PATH, radiance.h:7)"""
+    _check(_lib.lib().rdx_shader_include_path(str(path).encode() if path else None))
+
+
 def CreatePipeline(pipelineCreateInfo):
     return pipelineCreateInfo
 
