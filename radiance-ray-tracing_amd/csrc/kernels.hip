@@ -925,7 +925,10 @@ struct ShadowPolicy {
         bool occluded = false;
         if (ps.shO[i].w != 0.0f) {
             Payload sp; sp.hit = false;
-            if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[b.inst].SBTOffset + 2, sp, hh, sv, Ldir, 0, 0, 0, false); }
+            // (the cooperative engines only run scenes whose instances all have SBTOffset 0 -- others go to the reference-order
+            //  kernel, rdx_runtime.cpp view_of -- so the row is the constant 2 and the switch folds to `shadow`; with the
+            //  instance's offset read at run time the whole `material` shader was compiled into the traversal kernels)
+            if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit(2, sp, hh, sv, Ldir, 0, 0, 0, false); }
             else callMiss(4, sp);
             occluded = sp.hit;
         }
@@ -1080,7 +1083,7 @@ struct PathPolicy {
         }
         // the shadow query is answered: hit -> closest-hit row 2 `shadow`, miss -> row 4 `shadowMiss`
         Payload sp; sp.hit = false;
-        if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit((int)A.insts[b.inst].SBTOffset + 2, sp, hh, sv, Ldir, 0, 0, 0, false); }
+        if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit(2, sp, hh, sv, Ldir, 0, 0, 0, false); }      // SBTOffset is 0 on this engine, see ShadowPolicy
         else callMiss(4, sp);
         const float4 c = sp.hit ? ps.colSh[i] : ps.colLit[i];
         return advance(i, mk3(c.x, c.y, c.z), o, d, anyHit, st);

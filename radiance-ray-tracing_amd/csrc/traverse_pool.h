@@ -111,14 +111,19 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     // Bounded loop: the step selection below is meant to make progress on every iteration; should a logic error ever break
     // that, the wave leaves after POOL_MAX_ITER iterations and raises the status word the host checks after the frame
     // (rdx_trace_rays then returns an error) instead of hanging the GPU.  One scalar add + compare per iteration.
-    uint32_t iter = 0;
+    bool finished = false;
 #ifdef COOP_STATS
     uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // as traverse_coop.h; kind 6 = pool step
     uint32_t stState[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#ifdef POOL_WATCHDOG_V1
+    uint32_t iter = 0;
     for (;;) {
         iter = __builtin_amdgcn_readfirstlane(iter + 1u);
-        if (iter > POOL_MAX_ITER) { if (lane == 0 && A.status) atomicOr(A.status, 1u); break; }
+        if (iter > POOL_MAX_ITER) break;
+#else
+    for (uint32_t iter = 0; iter < POOL_MAX_ITER; ++iter) {
+#endif
         // a lane whose instance has left the pool moves on along its top-level stack
         if (tcur == POOL_INBLAS && pendN[lane] == 0u) POOL_TPOP();
         if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }
@@ -199,7 +204,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         }
         if (!workAny) {
             if (qTail != qHead) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
-            if (__ballot(rayIdx != COOP_NONE) == 0ull) break;      // exhausted, every lane free, queue and pool empty
+            if (__ballot(rayIdx != COOP_NONE) == 0ull) { finished = true; break; }      // exhausted, every lane free, queue and pool empty
             continue;                                              // lanes still finishing: next round hands them over
         }
         if (qTail - qHead >= POOL_TEST_MIN) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
@@ -443,6 +448,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         // (not reached: with an empty pool one of the two top-level branches above is always taken)
         if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
     }
+    if (!finished && lane == 0 && A.status) atomicOr(A.status, 1u);       // the iteration bound was hit: the host reports an error
 #ifdef COOP_STATS
     if (lane < 8u) atomicAdd(&g_coop_state[lane], (unsigned long long)stState[lane]);
     if (lane < 7u) { atomicAdd(&g_coop_stats[lane], (unsigned long long)statN[lane]); atomicAdd(&g_coop_stats[8u + lane], (unsigned long long)statL[lane]); }
