@@ -138,12 +138,11 @@ struct CoopLds {
     uint32_t* pend;                  // [64] helpers still walking for the ray owned by this lane
 };
 
-// branch-free Möller–Trumbore (radiance.cl:211-251) + the accept window of radiance.cl:90-91
-__device__ __forceinline__ bool coop_triangle(const AccelView& A, uint32_t slot, f3 ro, f3 rd, float tmin, float tmax,
-                                              float& tOut, float& b1Out, float& b2Out)
+// branch-free Möller–Trumbore (radiance.cl:211-251) + the accept window of radiance.cl:90-91, on a triangle record already in
+// registers (q0 = v0 | primID, q1 = e1, q2 = e2)
+__device__ __forceinline__ bool coop_triangle_regs(float4 q0, float4 q1, float4 q2, f3 ro, f3 rd, float tmin, float tmax,
+                                                   float& tOut, float& b1Out, float& b2Out)
 {
-    const float4* tp = reinterpret_cast<const float4*>(A.tris + slot);
-    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     const f3 e1 = mk3(q1.x, q1.y, q1.z), e2 = mk3(q2.x, q2.y, q2.z);
     const f3 rce2 = cross3(rd, e2);
     const float det = dot3(e1, rce2);
@@ -155,6 +154,12 @@ __device__ __forceinline__ bool coop_triangle(const AccelView& A, uint32_t slot,
     const float t = inv_det * dot3(e2, sce1);
     tOut = t; b1Out = b1; b2Out = b2;
     return (det != 0) & !(b1 < 0 || b1 > 1) & !(b2 < 0 || b1 + b2 > 1) & (t > 0) & (t > tmin) & (t < tmax);
+}
+__device__ __forceinline__ bool coop_triangle(const AccelView& A, uint32_t slot, f3 ro, f3 rd, float tmin, float tmax,
+                                              float& tOut, float& b1Out, float& b2Out)
+{
+    const float4* tp = reinterpret_cast<const float4*>(A.tris + slot);
+    return coop_triangle_regs(tp[0], tp[1], tp[2], ro, rd, tmin, tmax, tOut, b1Out, b2Out);
 }
 
 // one test step: up to 64 queued (walking lane, triangle) pairs, one per lane.  The object-space ray of an entry is
@@ -173,6 +178,10 @@ __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds
 #endif
     const uint32_t e = lane < n ? L.queue[(qHead + lane) & (COOP_QCAP - 1u)] : (lane << COOP_LANE_SHIFT);
     const uint32_t wl = e >> COOP_LANE_SHIFT;
+    // the triangle record is requested FIRST (idle lanes read slot 0): its ~1 us of memory latency then runs beside the lane
+    // shuffles below instead of behind them -- the LDS crossbar was on the critical path of every step
+    const float4* tp = reinterpret_cast<const float4*>(A.tris + (e & COOP_SLOT_MASK));
+    const float4 tq0 = tp[0], tq1 = tp[1], tq2 = tp[2];
     const uint32_t cpar = __shfl(par, wl);
     uint32_t w = __shfl(w6, wl);
     f3 ro = mk3(__shfl(R.o.x, wl), __shfl(R.o.y, wl), __shfl(R.o.z, wl));
@@ -186,7 +195,7 @@ __device__ __forceinline__ void coop_test_step(const AccelView& A, const CoopLds
             w = __float_as_uint(rs[6 * 64]);
         }
         float t, b1, b2;
-        if (coop_triangle(A, slot, ro, rd, tmin, tmax, t, b1, b2)) {
+        if (coop_triangle_regs(tq0, tq1, tq2, ro, rd, tmin, tmax, t, b1, b2)) {
             const uint32_t inst = w & ((1u << COOP_OWNER_SHIFT) - 1u);
             const uint32_t low = (inst << COOP_INST_SHIFT) | (slot - A.insts[inst]._p0);      // BLAS-local triangle slot
             const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | low;

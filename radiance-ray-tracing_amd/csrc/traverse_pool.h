@@ -386,13 +386,23 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             const uint32_t item = valid ? pool[poolTop - 1u - lane] : (lane << POOL_LANE_SHIFT);
             poolTop -= npop;
             const uint32_t wl = item >> POOL_LANE_SHIFT;
+            // the wide node is requested FIRST (idle lanes read node 0), so that its memory latency runs beside the lane shuffles
+            // below instead of behind them
+            const float4* wp = reinterpret_cast<const float4*>(A.wide + (item & POOL_NODE_MASK));
+            const float4 l0 = wp[0], l1 = wp[1], r0 = wp[2], r1 = wp[3];
             // the object-space ray of the item's owner, from its registers
             const uint32_t myFlags = (R.exactOnly ? 1u : 0u) | (par << 1) | (anyHit ? 4u : 0u);
             const uint32_t qf = __shfl(myFlags, wl);
             RayInst Q;
             Q.o = mk3(__shfl(R.o.x, wl), __shfl(R.o.y, wl), __shfl(R.o.z, wl));
             Q.d = mk3(__shfl(R.d.x, wl), __shfl(R.d.y, wl), __shfl(R.d.z, wl));
+#ifdef POOL_RCP_SHUFFLE
             Q.rcp = mk3(__shfl(R.rcp.x, wl), __shfl(R.rcp.y, wl), __shfl(R.rcp.z, wl));
+#else
+            // 1/d recomputed from the shuffled direction (three v_rcp_f32, the same values the owner computed) instead of
+            // three more lane shuffles: the VALU has slots to spare, the LDS crossbar is on the critical path
+            Q.rcp = mk3(__builtin_amdgcn_rcpf(Q.d.x), __builtin_amdgcn_rcpf(Q.d.y), __builtin_amdgcn_rcpf(Q.d.z));
+#endif
             Q.exactOnly = (qf & 1u) != 0u;
             uint32_t cntL = 0, stL = 0, cntR = 0, stR = 0, pushL = COOP_NONE, pushR = COOP_NONE;
             int delta = 0;
@@ -401,8 +411,6 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 const uint32_t hb = reinterpret_cast<const uint32_t*>(L.best)[2u * wl + 1u];     // t bits of the owner's best candidate
                 const bool dropIt = (REC != 1) && (qf & 4u) && hb != 0xffffffffu;           // shadow ray already answered
                 if (!dropIt) {
-                    const float4* wp = reinterpret_cast<const float4*>(A.wide + (item & POOL_NODE_MASK));
-                    const float4 l0 = wp[0], l1 = wp[1], r0 = wp[2], r1 = wp[3];
                     const uint32_t ld0 = __float_as_uint(l0.w), ld1 = __float_as_uint(l1.w);
                     const uint32_t rd0 = __float_as_uint(r0.w), rd1 = __float_as_uint(r1.w);
                     if (CULL) {
