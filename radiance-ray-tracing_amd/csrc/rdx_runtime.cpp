@@ -426,7 +426,8 @@ int derive_accel(rdx_buffer_s* tb)
     {
         uint32_t masks = 0;
         for (uint32_t i = 0; i < nTop; ++i) if (tnodes[i].w0 & LEAF_BIT) masks += ((tnodes[i].w0 & 0x7fffffffu) + 15u) / 16u;
-        ac->topFlat = (nTop <= 64 && masks <= 24) ? nTop : 0u;
+        // flat top level: <= 64 nodes (one reach bit each); the pending instances of a ray are a bitmap of <= 8 words per lane
+        ac->topFlat = (nTop <= 64 && nInst <= 256) ? nTop : 0u;
         // spare word of a top-level leaf: it holds instances whose BLAS is a single leaf of <= 8 triangles (pool engine)
         for (uint32_t i = 0; i < nTop; ++i) {
             dT[i].w3 = 0;
@@ -436,7 +437,8 @@ int derive_accel(rdx_buffer_s* tb)
                 if ((di.rootDesc1 & WIDE_LEAF) && (di.rootDesc1 & 0x7fffffffu) <= 8u) { dT[i].w3 = 1; ac->leafRoots = true; }
             }
         }
-        ac->topFlatNeed = masks + 1u;
+        ac->topFlatNeed = std::max(1u, (nInst + 31u) / 32u);       // words per lane of the pending-instance bitmap
+        (void)masks;
     }
     ac->blasNeed = maxBlasCoop;
     ac->blasNeedAny = maxBlasAny;
@@ -485,7 +487,7 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.cull = (v.kernel == 3 && (g.cull > 0 || (g.cull < 0 && acc(tb)->nWide >= 16384u))) ? 1u : 0u;
     v.topNeed = acc(tb)->topNeed; v.blasNeed = v.cull ? acc(tb)->blasNeedAny : acc(tb)->blasNeed;
     v.topFlat = g.topFlat ? acc(tb)->topFlat : 0u;
-    if (v.topFlat) v.topNeed = std::max(v.topNeed, acc(tb)->topFlatNeed);
+    if (v.topFlat) v.topNeed = acc(tb)->topFlatNeed;          // flat top level: words per lane of the pending-instance bitmap
     v.leafRoots = (v.topFlat && g.inlineLeafRoots && acc(tb)->leafRoots) ? 1u : 0u;
     return v;
 }

@@ -26,13 +26,42 @@ namespace rdx {
 #ifndef POOL_LDS_WORDS
 #define POOL_LDS_WORDS 2048u
 #endif
-__host__ __device__ inline uint32_t pool_fixed_words() { return 64u + COOP_QCAP + COOP_RAY_WORDS * 64u + 128u; }
+// ... and no more than POOL_CAP_MAX entries even when LDS would allow it: a smaller pool throttles the breadth of the walk
+// (fewer items popped per step once it fills), which keeps a ray's subtree closer to depth-first order -- better for the culled
+// walk and for cache locality.  Measured with the bitmap top level (tools/gpu_pool_var.sh, ms per 1080p frame, sample1 /
+// Sponza-class / 10.4 M triangles): 256 -> 15.5 / 32.4 / 84.4, 384 -> 14.5 / 32.3 / 83.5, 512 -> 14.6 / 32.8 / 83.7,
+// LDS-bound 832 -> 14.4 / 34.6 / 88.6.
+#ifndef POOL_CAP_MAX
+#define POOL_CAP_MAX 384u
+#endif
+// POOL_RAYS_LDS: the object-space rays live in LDS -- two slots of 8 words per lane (o.xyz | instance slot, d.xyz | flags), the
+// slot of the instance being walked and the one of the instance left before it, whose queued tests may still be pending --
+// and a pool / test step reads the ray of its item with two 128-bit LDS loads instead of fetching it from the owner's
+// registers with 7-8 lane shuffles.  The slot index (lane * 2 + parity) is the top 7 bits of a pool item / queue entry.
+#ifndef POOL_RAYS_LDS
+#define POOL_RAYS_LDS 0
+#endif
+#if POOL_RAYS_LDS
+#define POOL_QCAP 256u                 // queue ring: one enqueue (64 lanes x POOL_PIECE) must fit
+#define POOL_PIECE 4u
+#define POOL_PIECE_BITS 3u
+#define POOL_RAY_LDS_WORDS (2u * 64u * 8u)
+#define POOL_SLOT_SHIFT 25u            // pool item = ray slot << 25 | wide-node index
+#else
+#define POOL_QCAP COOP_QCAP
+#define POOL_PIECE 8u
+#define POOL_PIECE_BITS 4u
+#define POOL_RAY_LDS_WORDS (COOP_RAY_WORDS * 64u)
+#endif
+static_assert(POOL_QCAP >= 64u * POOL_PIECE && (POOL_QCAP & (POOL_QCAP - 1u)) == 0u, "queue ring too small for one enqueue");
+__host__ __device__ inline uint32_t pool_fixed_words() { return 64u + POOL_QCAP + POOL_RAY_LDS_WORDS + 128u; }
 __host__ __device__ inline uint32_t pool_cap(uint32_t topNeed, uint32_t blasNeed)
 {
     const uint32_t used = topNeed * 64u + pool_fixed_words();
     const uint32_t budget = used < POOL_LDS_WORDS ? ((POOL_LDS_WORDS - used) & ~63u) : 0u;
     uint32_t cap = 64u * (blasNeed ? blasNeed : 1u);
     if (cap > budget) cap = budget;
+    if (cap > POOL_CAP_MAX) cap = POOL_CAP_MAX;
     const uint32_t least = (64u + blasNeed + 3u + 64u + 63u) & ~63u;       // 64 roots + RESERVE + one wide step
     return cap < least ? least : cap;
 }
@@ -41,8 +70,13 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
     return topNeed * 64u + pool_cap(topNeed, blasNeed) + pool_fixed_words();
 }
 
-#define POOL_LANE_SHIFT 26u            // pool item = owning lane << 26 | wide-node index
+#define POOL_LANE_SHIFT 26u            // pool item = owning lane << 26 | (POOL_RAYS_LDS: instance parity << 25 |) wide-node index
+#if POOL_RAYS_LDS
+#define POOL_NODE_MASK ((1u << POOL_SLOT_SHIFT) - 1u)
+#else
 #define POOL_NODE_MASK ((1u << POOL_LANE_SHIFT) - 1u)
+#endif
+static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rule (derive_accel) must match the pool item layout");
 #define POOL_INBLAS 0xfffffffeu        // top-level cursor of a lane whose instance is in the pool
 #ifndef POOL_TEST_MIN
 #define POOL_TEST_MIN 48u              // queued triangle tests a test step waits for (32-64: flat within 1.5 %; 96-128: +2-5 %)
@@ -58,6 +92,50 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
 #endif
 #ifndef POOL_IDLE_MIN
 #define POOL_IDLE_MIN 32               // finished / free lanes a hand-over step waits for (16: +13 %, 24: +4 %, 40-48: +0-3 % frame time)
+#endif
+
+
+#if POOL_RAYS_LDS
+// one test step: up to 64 queued (ray slot, triangle) pairs, one per lane; the ray comes from the entry's LDS slot
+__device__ __forceinline__ void pool_test_step(const AccelView& A, const uint32_t* queue, const float4* rays, unsigned long long* best,
+                                               uint32_t lane, uint32_t& qHead, uint32_t qTail, float tmin, float tmax)
+{
+    const uint32_t n = min(64u, qTail - qHead);
+#ifdef COOP_STATS
+    if (lane == 0) { atomicAdd(&g_coop_stats[7], 1ull); atomicAdd(&g_coop_stats[15], (unsigned long long)n); }
+#endif
+    const uint32_t e = lane < n ? queue[(qHead + lane) & (POOL_QCAP - 1u)] : (lane << COOP_LANE_SHIFT);
+    const float4* tp = reinterpret_cast<const float4*>(A.tris + (e & COOP_SLOT_MASK));      // requested first (idle lanes read slot 0)
+    const float4 tq0 = tp[0], tq1 = tp[1], tq2 = tp[2];
+    const float4* rs = rays + 2u * (e >> COOP_PAR_SHIFT);
+    const float4 ra = rs[0], rb = rs[1];
+    if (lane < n) {
+        float t, b1, b2;
+        if (coop_triangle_regs(tq0, tq1, tq2, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), tmin, tmax, t, b1, b2)) {
+            const uint32_t inst = __float_as_uint(ra.w);
+            const uint32_t low = (inst << COOP_INST_SHIFT) | ((e & COOP_SLOT_MASK) - A.insts[inst]._p0);      // BLAS-local triangle slot
+            atomicMin(&best[e >> COOP_LANE_SHIFT], ((unsigned long long)__float_as_uint(t) << 32) | low);
+        }
+    }
+    qHead += n;
+}
+// append `cnt` (0..POOL_PIECE) consecutive triangle slots starting at `start` for every lane; wave-uniform control
+__device__ __forceinline__ void pool_enqueue(const AccelView& A, uint32_t* queue, const float4* rays, unsigned long long* best, uint32_t lane,
+                                             uint32_t tagBits, uint32_t cnt, uint32_t start, uint32_t& qHead, uint32_t& qTail, float tmin, float tmax)
+{
+    uint32_t pre = 0, total = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < POOL_PIECE_BITS; ++b) {
+        const unsigned long long m = __ballot((cnt >> b) & 1u);
+        pre += lanes_below(m) << b;
+        total += (uint32_t)__popcll(m) << b;
+    }
+    if (total == 0) return;
+    while (qTail - qHead + total > POOL_QCAP) pool_test_step(A, queue, rays, best, lane, qHead, qTail, tmin, tmax);
+    const uint32_t at = qTail + pre;
+    for (uint32_t k = 0; k < cnt; ++k) queue[(at + k) & (POOL_QCAP - 1u)] = tagBits | (start + k);
+    qTail += total;
+}
 #endif
 
 // INL: the scene has instances whose BLAS is a single leaf of <= 8 triangles; they are handled inside the top-level step
@@ -79,9 +157,17 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     CoopLds L;
     L.stack = nullptr;
     L.queue = pendN + 64;
-    L.ray = reinterpret_cast<float*>(L.queue + COOP_QCAP);
-    L.best = reinterpret_cast<unsigned long long*>(L.ray + COOP_RAY_WORDS * 64u);
+    L.ray = reinterpret_cast<float*>(L.queue + POOL_QCAP);
+    L.best = reinterpret_cast<unsigned long long*>(L.ray + POOL_RAY_LDS_WORDS);
     L.pend = nullptr;
+#if POOL_RAYS_LDS
+    float4* rays = reinterpret_cast<float4*>(L.ray);       // [lane * 2 + parity][2]
+#define POOL_TEST() pool_test_step(A, L.queue, rays, L.best, lane, qHead, qTail, tmin, tmax)
+#define POOL_ENQ(TAG, CNT, START) pool_enqueue(A, L.queue, rays, L.best, lane, TAG, CNT, START, qHead, qTail, tmin, tmax)
+#else
+#define POOL_TEST() coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6)
+#define POOL_ENQ(TAG, CNT, START) coop_enqueue(A, L, lane, TAG, CNT, START, qHead, qTail, tmin, tmax, R, par, w6)
+#endif
     pendN[lane] = 0u;
 
     const uint32_t nWavesGrid = gridDim.x * (blockDim.x >> 6);
@@ -93,15 +179,42 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     uint32_t resBase = 0, resEnd = 0;
     uint32_t rayIdx = COOP_NONE;
     uint32_t tcur = COOP_NONE, tsp = 0;                    // top-level cursor / stack pointer
-    uint32_t par = 0, w6 = lane << COOP_OWNER_SHIFT;
+    uint32_t par = 0;
+#if !POOL_RAYS_LDS
+    uint32_t w6 = lane << COOP_OWNER_SHIFT;
+#endif
     uint32_t markPrev = 0, finMark = 0;
     bool finishing = false, anyHit = (REC == 2);
     typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
+#if !POOL_RAYS_LDS
     RayInst R;
     R.o = o; R.d = d; R.rcp = mk3(0.f, 0.f, 0.f); R.exactOnly = true;
+#endif
 
-#define POOL_TPOP() do { if (tsp == 0) tcur = COOP_NONE; else { --tsp; tcur = tstack[tsp * 64u]; } } while (0)
+    // Flat top level (A.topFlat != 0): the instances a ray still has to enter are a per-lane BITMAP over the instance slots in
+    // LDS (A.topNeed = ceil(instances / 32) words per lane) plus their count in a register, instead of a stack of mask
+    // entries -- a quarter to a tenth of the LDS (25 instances: 1 word instead of 9 per lane), which is residency.
+    const bool flatTop = A.topFlat != 0u;
+    uint32_t instLeft = 0;
+    if (flatTop) for (uint32_t w = 0; w < A.topNeed; ++w) tstack[w * 64u] = 0u;
+#define POOL_INSTBITS (TAG_INST | IDX_MASK)            // top-level cursor in flat mode: "take the next instance from the bitmap"
+#define POOL_TPOP() do {                                                                               \
+        if (flatTop) tcur = instLeft ? POOL_INSTBITS : COOP_NONE;                                      \
+        else if (tsp == 0) tcur = COOP_NONE; else { --tsp; tcur = tstack[tsp * 64u]; }                 \
+    } while (0)
+#define POOL_DROP() do {       /* the ray needs nothing more from the top level (shadow ray answered) */ \
+        tcur = COOP_NONE; tsp = 0;                                                                     \
+        if (flatTop && instLeft) { for (uint32_t w_ = 0; w_ < A.topNeed; ++w_) tstack[w_ * 64u] = 0u; instLeft = 0; } \
+    } while (0)
+#define POOL_FILE_INSTANCES(M16, FIRST) do {            /* up to 16 instances FIRST.. (wave-uniform) with lane mask M16 */ \
+        if (flatTop) {                                                                                 \
+            const uint32_t wi_ = (FIRST) >> 5, sh_ = (FIRST) & 31u;                                    \
+            atomicOr(&tstack[wi_ * 64u], (M16) << sh_);                                                \
+            if (sh_ > 16u && ((M16) >> (32u - sh_)) != 0u) atomicOr(&tstack[(wi_ + 1u) * 64u], (M16) >> (32u - sh_)); \
+            instLeft += (uint32_t)__popc(M16);                                                         \
+        } else { tstack[tsp * 64u] = TAG_INST | ((M16) << COOP_IMASK_SHIFT) | (FIRST); ++tsp; }        \
+    } while (0)
 #define POOL_START_RAY(WALK) do {                                                                      \
         L.best[lane] = ~0ull;                                                                          \
         tsp = 0; par = 0; markPrev = qHead; finishing = false;                                         \
@@ -203,16 +316,16 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             continue;
         }
         if (!workAny) {
-            if (qTail != qHead) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            if (qTail != qHead) { POOL_TEST(); continue; }
             if (__ballot(rayIdx != COOP_NONE) == 0ull) { finished = true; break; }      // exhausted, every lane free, queue and pool empty
             continue;                                              // lanes still finishing: next round hands them over
         }
-        if (qTail - qHead >= POOL_TEST_MIN) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+        if (qTail - qHead >= POOL_TEST_MIN) { POOL_TEST(); continue; }
 
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------------------
         if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
             COOP_STAT(4, nTop);
-            if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
+            if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) POOL_DROP(); }
             if (A.topFlat != 0u) {
                 // Small top-level tree (<= 64 nodes): no walk.  Every node is looked at once, in index order (parents come
                 // before their children, DFS pre-order), by all lanes of the step together -- the node is the same for all
@@ -265,14 +378,14 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                                             }
                                         } else if (coop_inst_pretest(I, o, W.rcp, oMax, preOK)) m16 |= 1u << k;
                                     }
-                                    if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                                    if (m16) POOL_FILE_INSTANCES(m16, w.y + b0);
                                 }
                             } else {
                                 for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
                                     uint32_t m16 = 0;
                                     for (uint32_t k = 0; k < min(16u, count - b0); ++k)
                                         if (coop_inst_pretest(A.insts[w.y + b0 + k], o, W.rcp, oMax, preOK)) m16 |= 1u << k;
-                                    if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                                    if (m16) POOL_FILE_INSTANCES(m16, w.y + b0);
                                 }
                             }
                         }
@@ -303,7 +416,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                             uint32_t m16 = 0;
                             for (uint32_t i = 0; i < min(16u, count - b0); ++i)
                                 if (coop_inst_pretest(A.insts[w.y + b0 + i], o, W.rcp, oMax, preOK)) m16 |= 1u << i;
-                            if (m16) { tstack[tsp * 64u] = TAG_INST | (m16 << COOP_IMASK_SHIFT) | (w.y + b0); ++tsp; }
+                            if (m16) POOL_FILE_INSTANCES(m16, w.y + b0);
                         }
                     }
                     POOL_TPOP();
@@ -314,13 +427,20 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         // ---- instance entry (radiance.cl:161-169): the BLAS root goes into the pool ----------------------------------
         if (nInst > 0 && nInst * POOL_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE) {
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
-            if (__ballot(ready) == 0ull) { coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6); continue; }
+            if (__ballot(ready) == 0ull) { POOL_TEST(); continue; }
             COOP_STAT(5, __popcll(__ballot(ready)));
-            if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) { tcur = COOP_NONE; tsp = 0; } }
+            if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) POOL_DROP(); }
             uint32_t cntE = 0, stE = 0, rootNode = COOP_NONE;
             if (ready && tcur != COOP_NONE) {
                 uint32_t ci = tcur & COOP_IFIRST_MASK;
-                {
+                if (flatTop) {       // the lowest pending instance of the bitmap
+                    ci = 0;
+                    for (uint32_t w_ = 0; w_ < A.topNeed; ++w_) {
+                        const uint32_t v_ = tstack[w_ * 64u];
+                        if (v_) { ci = w_ * 32u + (uint32_t)__ffs((int)v_) - 1u; tstack[w_ * 64u] = v_ & (v_ - 1u); break; }
+                    }
+                    --instLeft;
+                } else {
                     const uint32_t m16 = (tcur >> COOP_IMASK_SHIFT) & 0xffffu, rest = m16 & (m16 - 1u);
                     ci += (uint32_t)__ffs((int)m16) - 1u;
                     if (rest) { tstack[tsp * 64u] = TAG_INST | (rest << COOP_IMASK_SHIFT) | (tcur & COOP_IFIRST_MASK); ++tsp; }
@@ -331,6 +451,23 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 *reinterpret_cast<float4*>(m + 4) = ip[1];
                 *reinterpret_cast<float4*>(m + 8) = ip[2];
                 *reinterpret_cast<float4*>(m + 12) = ip[3];
+#if POOL_RAYS_LDS
+                // the ray in the instance's space goes into this lane's OTHER slot: the slot of the instance being left keeps
+                // serving its queued tests, and the tests that used the other slot (the instance before that) are done (`ready`)
+                RayInst R;
+                par ^= 1u;
+                R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
+                R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
+                R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
+                const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
+                const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
+                R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
+                {
+                    float4* rs = rays + 2u * (lane * 2u + par);
+                    rs[0] = make_float4(R.o.x, R.o.y, R.o.z, __uint_as_float(ci));
+                    rs[1] = make_float4(R.d.x, R.d.y, R.d.z, __uint_as_float((R.exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)));
+                }
+#else
                 {   // park the ray of the instance being left: queued tests of it may still be pending
                     float* rs = L.ray + lane;
                     rs[0 * 64] = R.o.x; rs[1 * 64] = R.o.y; rs[2 * 64] = R.o.z;
@@ -344,9 +481,12 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
                 const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
                 R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
+#endif
                 const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
                 markPrev = qTail;            // everything queued so far belongs to instances being left
+#if !POOL_RAYS_LDS
                 par ^= 1u;
+#endif
                 if (rdsc.y & WIDE_LEAF) {
                     cntE = rdsc.y & 0x7fffffffu; stE = rdsc.x;
                     POOL_TPOP();
@@ -366,13 +506,17 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             }
             {
                 const unsigned long long pm = __ballot(rootNode != COOP_NONE);
+#if POOL_RAYS_LDS
+                if (rootNode != COOP_NONE) pool[poolTop + lanes_below(pm)] = ((lane * 2u + par) << POOL_SLOT_SHIFT) | (rootNode & POOL_NODE_MASK);
+#else
                 if (rootNode != COOP_NONE) pool[poolTop + lanes_below(pm)] = (lane << POOL_LANE_SHIFT) | (rootNode & POOL_NODE_MASK);
+#endif
                 poolTop += (uint32_t)__popcll(pm);
             }
             const uint32_t tagBits = (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT);
             while (__any(cntE != 0u)) {      // (a leaf of more than 8 triangles goes in pieces)
-                const uint32_t c = min(cntE, 8u);
-                coop_enqueue(A, L, lane, tagBits, c, stE, qHead, qTail, tmin, tmax, R, par, w6);
+                const uint32_t c = min(cntE, POOL_PIECE);
+                POOL_ENQ(tagBits, c, stE);
                 stE += c; cntE -= c;
             }
             continue;
@@ -390,6 +534,18 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             // below instead of behind them
             const float4* wp = reinterpret_cast<const float4*>(A.wide + (item & POOL_NODE_MASK));
             const float4 l0 = wp[0], l1 = wp[1], r0 = wp[2], r1 = wp[3];
+#if POOL_RAYS_LDS
+            // the object-space ray of the item, from its LDS slot
+            const uint32_t slotBits = item & ~POOL_NODE_MASK;
+            const float4* rs = rays + 2u * (item >> POOL_SLOT_SHIFT);
+            const float4 ra = rs[0], rb = rs[1];
+            const uint32_t qf = __float_as_uint(rb.w);
+            RayInst Q;
+            Q.o = mk3(ra.x, ra.y, ra.z);
+            Q.d = mk3(rb.x, rb.y, rb.z);
+            Q.rcp = mk3(__builtin_amdgcn_rcpf(Q.d.x), __builtin_amdgcn_rcpf(Q.d.y), __builtin_amdgcn_rcpf(Q.d.z));
+#else
+            const uint32_t slotBits = wl << POOL_LANE_SHIFT;
             // the object-space ray of the item's owner, from its registers
             const uint32_t myFlags = (R.exactOnly ? 1u : 0u) | (par << 1) | (anyHit ? 4u : 0u);
             const uint32_t qf = __shfl(myFlags, wl);
@@ -402,6 +558,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             // 1/d recomputed from the shuffled direction (three v_rcp_f32, the same values the owner computed) instead of
             // three more lane shuffles: the VALU has slots to spare, the LDS crossbar is on the critical path
             Q.rcp = mk3(__builtin_amdgcn_rcpf(Q.d.x), __builtin_amdgcn_rcpf(Q.d.y), __builtin_amdgcn_rcpf(Q.d.z));
+#endif
 #endif
             Q.exactOnly = (qf & 1u) != 0u;
             uint32_t cntL = 0, stL = 0, cntR = 0, stR = 0, pushL = COOP_NONE, pushR = COOP_NONE;
@@ -438,23 +595,27 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 // (CULL: the nearer child on top instead; the pool is then sized for any order)
                 const unsigned long long mR = __ballot(pushR != COOP_NONE), mL = __ballot(pushL != COOP_NONE);
                 const uint32_t nR = (uint32_t)__popcll(mR);
-                if (pushR != COOP_NONE) pool[poolTop + lanes_below(mR)] = (wl << POOL_LANE_SHIFT) | (pushR & POOL_NODE_MASK);
-                if (pushL != COOP_NONE) pool[poolTop + nR + lanes_below(mL)] = (wl << POOL_LANE_SHIFT) | (pushL & POOL_NODE_MASK);
+                if (pushR != COOP_NONE) pool[poolTop + lanes_below(mR)] = slotBits | (pushR & POOL_NODE_MASK);
+                if (pushL != COOP_NONE) pool[poolTop + nR + lanes_below(mL)] = slotBits | (pushL & POOL_NODE_MASK);
                 poolTop += nR + (uint32_t)__popcll(mL);
             }
             if (valid && delta != 0) atomicAdd(&pendN[wl], (uint32_t)delta);
+#if POOL_RAYS_LDS
+            const uint32_t tagBits = slotBits;
+#else
             const uint32_t tagBits = (wl << COOP_LANE_SHIFT) | (((qf >> 1) & 1u) << COOP_PAR_SHIFT);
+#endif
             while (__any((cntL | cntR) != 0u)) {
-                const uint32_t cl = min(cntL, 8u), cr = min(cntR, 8u);
-                coop_enqueue(A, L, lane, tagBits, cl, stL, qHead, qTail, tmin, tmax, R, par, w6);
-                coop_enqueue(A, L, lane, tagBits, cr, stR, qHead, qTail, tmin, tmax, R, par, w6);
+                const uint32_t cl = min(cntL, POOL_PIECE), cr = min(cntR, POOL_PIECE);
+                POOL_ENQ(tagBits, cl, stL);
+                POOL_ENQ(tagBits, cr, stR);
                 stL += cl; cntL -= cl; stR += cr; cntR -= cr;
             }
-            if (qTail - qHead >= POOL_TEST_MIN) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
+            if (qTail - qHead >= POOL_TEST_MIN) POOL_TEST();
             continue;
         }
         // (not reached: with an empty pool one of the two top-level branches above is always taken)
-        if (qTail != qHead) coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6);
+        if (qTail != qHead) POOL_TEST();
     }
     if (!finished && lane == 0 && A.status) atomicOr(A.status, 1u);       // the iteration bound was hit: the host reports an error
 #ifdef COOP_STATS
@@ -462,7 +623,12 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     if (lane < 7u) { atomicAdd(&g_coop_stats[lane], (unsigned long long)statN[lane]); atomicAdd(&g_coop_stats[8u + lane], (unsigned long long)statL[lane]); }
 #endif
     pol.retire(st);
+#undef POOL_TEST
+#undef POOL_ENQ
 #undef POOL_TPOP
+#undef POOL_DROP
+#undef POOL_FILE_INSTANCES
+#undef POOL_INSTBITS
 #undef POOL_START_RAY
 }
 
