@@ -28,7 +28,7 @@ struct AccelView {                 // derived traversal layout (see rdx_types.h)
 
 // limits of the cooperative engines' packed words, shared by the kernels (traverse_coop.h) and the host's fallback rule
 constexpr uint32_t RDX_COOP_MAX_TRI_SLOTS = 1u << 25;    // queue entry: lane << 26 | parity << 25 | absolute triangle slot
-constexpr uint32_t RDX_COOP_MAX_WIDE = 1u << 25;         // pool item: lane << 26 | instance parity << 25 | wide-node index
+constexpr uint32_t RDX_COOP_MAX_WIDE = 1u << 26;         // pool item: lane << 26 | wide-node index
 constexpr uint32_t RDX_COOP_MAX_INSTANCES = 1u << 10;    // key: instance slot << 22 | BLAS-local triangle slot
 constexpr uint32_t RDX_COOP_MAX_BLAS_TRIS = 1u << 22;
 constexpr uint32_t RDX_LDS_WORDS_PER_WAVE_MAX = 16384u;  // 64 KB per workgroup of one wave

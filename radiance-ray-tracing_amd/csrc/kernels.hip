@@ -880,6 +880,11 @@ __device__ __forceinline__ void write_hit_record(const AccelView& A, const Trace
 #define COOP_WPE 5
 #endif
 #define COOP_BOUNDS __launch_bounds__(RDX_BLOCK, COOP_WPE)
+// the pool engine keeps its rays in LDS (traverse_pool.h) and fits 80 VGPRs: 6 waves per SIMD
+#ifndef POOL_WPE
+#define POOL_WPE 6
+#endif
+#define POOL_BOUNDS __launch_bounds__(RDX_BLOCK, POOL_WPE)
 #define RDX_SINGLE_RAY_POLICY                                                                                   \
     struct State {};                                                                                             \
     static constexpr bool kShades = false;                                                                       \
@@ -985,7 +990,7 @@ k_fused_coop(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
 
 // ---- the same three launches on the shared-node-pool engine (traverse_pool.h, `kernel` option 3) ------------------------
 template <bool INL, bool CULL>
-__global__ void COOP_BOUNDS
+__global__ void POOL_BOUNDS
 k_extend_pool(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
 {
     ExtendPolicy pol{A, ps};
@@ -993,7 +998,7 @@ k_extend_pool(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, ui
 }
 
 template <bool INL, bool CULL>
-__global__ void COOP_BOUNDS
+__global__ void POOL_BOUNDS
 k_shadow_pool(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
               uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
@@ -1003,7 +1008,7 @@ k_shadow_pool(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restr
 }
 
 template <bool INL, bool CULL>
-__global__ void COOP_BOUNDS
+__global__ void POOL_BOUNDS
 k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
              uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
@@ -1160,7 +1165,7 @@ k_trace_batch_coop(AccelView A, const float* __restrict__ o, const float* __rest
 }
 
 template <bool INL, bool CULL>
-__global__ void COOP_BOUNDS
+__global__ void POOL_BOUNDS
 k_trace_batch_pool1(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
                     float tmin, float tmax, rdx_hit* __restrict__ out)
 {
@@ -1168,7 +1173,7 @@ k_trace_batch_pool1(AccelView A, const float* __restrict__ o, const float* __res
     traverse_pool<1, INL, CULL>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 template <bool INL, bool CULL>
-__global__ void COOP_BOUNDS
+__global__ void POOL_BOUNDS
 k_trace_batch_pool2(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
                     float tmin, float tmax, rdx_hit* __restrict__ out)
 {
@@ -1274,17 +1279,17 @@ void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& p
 }
 
 // threads per block for the cooperative kernels: per-wave LDS = stack + queue + ray table
-static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsBytes);
-static inline uint32_t coop_threads(uint32_t need, size_t& ldsBytes) { return coop_threads_words(coop_words_per_wave(need), ldsBytes); }
-static inline uint32_t pool_threads(const AccelView& av, size_t& ldsBytes) { return coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), ldsBytes); }
-static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsBytes)
+static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsBytes, uint32_t wpe);
+static inline uint32_t coop_threads(uint32_t need, size_t& ldsBytes) { return coop_threads_words(coop_words_per_wave(need), ldsBytes, COOP_WPE); }
+static inline uint32_t pool_threads(const AccelView& av, size_t& ldsBytes) { return coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), ldsBytes, POOL_WPE); }
+static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsBytes, uint32_t wpe)
 {
     // experiment knobs (tools/occupancy_probe.sh): RDX_COOP_THREADS = block size, RDX_COOP_LDS_PAD = extra LDS bytes per
     // wave (lowers the residency the LDS allows)
     static const int envThreads = std::getenv("RDX_COOP_THREADS") ? std::atoi(std::getenv("RDX_COOP_THREADS")) : 0;
     static const int envPad = std::getenv("RDX_COOP_LDS_PAD") ? std::atoi(std::getenv("RDX_COOP_LDS_PAD")) : 0;
     const size_t perWave = (size_t)wordsPerWave * 4 + (size_t)envPad;
-    // Residency is LDS-bound (tools/occupancy_probe.sh: frame time falls steadily up to the 5 waves / SIMD the
+    // Residency is LDS-bound (tools/occupancy_probe.sh: frame time falls steadily up to the `wpe` waves / SIMD the
     // registers allow), so take the block size -- 4 or 2 waves -- that packs the most waves into a CU's 160 KB.
     uint32_t threads = 64;
     if (envThreads >= 64) {
@@ -1295,7 +1300,7 @@ static inline uint32_t coop_threads_words(uint32_t wordsPerWave, size_t& ldsByte
         for (uint32_t t : {128u, 256u}) {      // on a tie the smaller block: measured faster (it also packs tighter)
             const size_t blk = perWave * (t / 64);
             if (blk > 64 * 1024) continue;
-            const uint32_t waves = std::min<uint32_t>((uint32_t)((160 * 1024) / blk) * (t / 64), 4u * COOP_WPE);
+            const uint32_t waves = std::min<uint32_t>((uint32_t)((160 * 1024) / blk) * (t / 64), 4u * wpe);
             if (waves > best) { best = waves; threads = t; }
         }
     }
@@ -1308,9 +1313,9 @@ static thread_local uint32_t g_gridShare = 1;       // host side: how many concu
 void set_grid_share(uint32_t groups) { g_gridShare = groups ? groups : 1; }
 
 // persistent grid: enough blocks to fill every CU at the LDS-limited residency, never more than the work
-static inline uint32_t coop_blocks(uint32_t nMax, uint32_t threads, size_t ldsBytes)
+static inline uint32_t coop_blocks(uint32_t nMax, uint32_t threads, size_t ldsBytes, uint32_t wpe = COOP_WPE)
 {
-    const uint32_t perCU = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(ldsBytes, 1), (64u * 4u * COOP_WPE) / threads));
+    const uint32_t perCU = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(ldsBytes, 1), (64u * 4u * wpe) / threads));
     // small launches: enough waves that each is handed COOP_MIN_QUOTA rays (its other lanes help, traverse_coop.h)
     const uint64_t spread = COOP_STEAL ? (uint64_t)nMax * (64u / COOP_MIN_QUOTA) : nMax;
     // launches of different sample groups share the GPU: each takes its part of the resident grid
@@ -1333,7 +1338,7 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
             else { if (av.cull) hipLaunchKernelGGL((K<false, true>), GRID, dim3(th), lds, st, __VA_ARGS__);                 \
                    else hipLaunchKernelGGL((K<false, false>), GRID, dim3(th), lds, st, __VA_ARGS__); }                      \
         } while (0)
-        RDX_POOL_LAUNCH(k_extend_pool, dim3(coop_blocks(nMax, th, lds)), av, ps, nPtr, counter, tmin, tmax);
+        RDX_POOL_LAUNCH(k_extend_pool, dim3(coop_blocks(nMax, th, lds, POOL_WPE)), av, ps, nPtr, counter, tmin, tmax);
         return;
     }
     if (!visit && av.kernel == 2) {
@@ -1376,7 +1381,7 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
     if (!nMax) return;
     if (!visit && av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
-        RDX_POOL_LAUNCH(k_shadow_pool, dim3(coop_blocks(nMax, th, lds)), av, sc, ps, nPtr, counter, lastBounce ? 1u : 0u, nPixels, sampleBase,
+        RDX_POOL_LAUNCH(k_shadow_pool, dim3(coop_blocks(nMax, th, lds, POOL_WPE)), av, sc, ps, nPtr, counter, lastBounce ? 1u : 0u, nPixels, sampleBase,
                         tmin, tmax);
         return;
     }
@@ -1401,7 +1406,7 @@ void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
     if (!mMax) return;
     if (av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
-        RDX_POOL_LAUNCH(k_fused_pool, dim3(coop_blocks(2u * mMax, th, lds)), av, sc, psShadow, psExtend, mPtr, counter, nPixels, sampleBase, tmin, tmax);
+        RDX_POOL_LAUNCH(k_fused_pool, dim3(coop_blocks(2u * mMax, th, lds, POOL_WPE)), av, sc, psShadow, psExtend, mPtr, counter, nPixels, sampleBase, tmin, tmax);
         return;
     }
     size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
@@ -1452,7 +1457,7 @@ void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, con
     if (!n) return;
     if (!visit && mode == 0 && av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
-        const dim3 gp(coop_blocks(n, th, lds));
+        const dim3 gp(coop_blocks(n, th, lds, POOL_WPE));
         if (rec == 2) RDX_POOL_LAUNCH(k_trace_batch_pool2, gp, av, o, d, n, counter, tmin, tmax, out);
         else RDX_POOL_LAUNCH(k_trace_batch_pool1, gp, av, o, d, n, counter, tmin, tmax, out);
         return;

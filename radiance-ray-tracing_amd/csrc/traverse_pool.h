@@ -1,12 +1,12 @@
-// traverse_pool.h -- the wave-cooperative traversal with a SHARED node pool (experimental engine, `kernel` option 3).
+// traverse_pool.h -- the wave-cooperative traversal with a SHARED node pool (the default engine, `kernel` option 3).
 //
 // tools/coop_stats.py shows where traverse_coop.h leaves lanes idle: a test step serves 62-64 lanes because any lane
 // may test any queued (ray, triangle) pair, but a node step only serves the lanes whose OWN ray holds a BLAS node at
 // that moment -- 29-33 of 64.  Here BLAS nodes get the treatment the triangles already have.  Nothing is culled by
 // the best t, so a pending (ray, node) pair is an independent work item whose only outputs are more such items and
 // queued triangle tests: all of a wave's pending BLAS nodes live in ONE LIFO pool in LDS and every pool step pops up
-// to 64 of them, whichever rays they belong to.  The lane that processes an item fetches the object-space ray of the
-// item's ray from the owning lane's registers by lane shuffles, runs the two slab tests of the wide node with the
+// to 64 of them, whichever rays they belong to.  The lane that processes an item reads the object-space ray of the
+// item from the owner's ray slot in LDS ("Rays in LDS" below), runs the two slab tests of the wide node with the
 // reference's decision rule, pushes inner children back, queues leaf triangles for the owner and adjusts the owner's
 // count of outstanding items (LDS atomic).  A lane is the top-level driver of its ray: it walks the TLAS and enters
 // instances itself (private stack of top-level entries), pushes the BLAS root into the pool and waits until its
@@ -21,10 +21,11 @@
 
 namespace rdx {
 
-// Pool capacity: 64 * BLAS stack need entries, but no more than lets the wave's LDS stay within 8 KB -- 20 waves per CU
-// (the engine lives on residency, tools/occupancy_probe.sh) -- and no less than an instance step needs to push 64 roots.
+// Pool capacity: 64 * BLAS stack need entries, but no more than lets the wave's LDS stay within 160 KB / 24 -- 6 waves per
+// SIMD, what the registers allow (the engine lives on residency, tools/occupancy_probe.sh) -- and no less than an instance
+// step needs to push 64 roots.
 #ifndef POOL_LDS_WORDS
-#define POOL_LDS_WORDS 2048u
+#define POOL_LDS_WORDS 1706u
 #endif
 // ... and no more than POOL_CAP_MAX entries even when LDS would allow it: a smaller pool throttles the breadth of the walk
 // (fewer items popped per step once it fills), which keeps a ray's subtree closer to depth-first order -- better for the culled
@@ -34,25 +35,23 @@ namespace rdx {
 #ifndef POOL_CAP_MAX
 #define POOL_CAP_MAX 384u
 #endif
-// POOL_RAYS_LDS: the object-space rays live in LDS -- two slots of 8 words per lane (o.xyz | instance slot, d.xyz | flags), the
-// slot of the instance being walked and the one of the instance left before it, whose queued tests may still be pending --
-// and a pool / test step reads the ray of its item with two 128-bit LDS loads instead of fetching it from the owner's
-// registers with 7-8 lane shuffles.  The slot index (lane * 2 + parity) is the top 7 bits of a pool item / queue entry.
-#ifndef POOL_RAYS_LDS
-#define POOL_RAYS_LDS 0
-#endif
-#if POOL_RAYS_LDS
-#define POOL_QCAP 256u                 // queue ring: one enqueue (64 lanes x POOL_PIECE) must fit
-#define POOL_PIECE 4u
+// Rays in LDS.  A lane's object-space ray lives in its LDS slot of 8 words -- rays[lane] = o.xyz | instance slot,
+// rays[64 + lane] = d.xyz | flags -- written when the lane enters an instance, and a pool / test step reads the ray of its item
+// with two 128-bit LDS loads.  (Until round 2 the ray stayed in the owning lane's registers and was fetched with 7-8 lane
+// shuffles per step: ds_bpermute sits on the critical path of every step, and the 10 registers are better spent on a sixth
+// wave per SIMD.)  There is ONE slot per lane: a lane enters its next instance only after the queued tests of the one it left
+// are done (`markPrev`).  Two slots (no such wait) measured 1.5 % faster at equal residency on the Sponza-class scene, but
+// cost the 512 words of LDS that, with the registers, stand between 5 and 6 waves per SIMD.  1080p frame, sample1 /
+// Sponza-class / 10.4 M triangles: shuffles 14.5 / 32.3 / 83.0 ms, two slots 14.0 / 30.0 / 82.7, one slot and 6 waves
+// 13.8 / 28.0 / 72.8 (7 waves: 14.5 / 28.0 / 73.9 -- spills).
+#ifndef POOL_PIECE
+#define POOL_PIECE 4u                  // triangles one enqueue call takes per lane (a leaf of more goes in pieces) ...
 #define POOL_PIECE_BITS 3u
-#define POOL_RAY_LDS_WORDS (2u * 64u * 8u)
-#define POOL_SLOT_SHIFT 25u            // pool item = ray slot << 25 | wide-node index
-#else
-#define POOL_QCAP COOP_QCAP
-#define POOL_PIECE 8u
-#define POOL_PIECE_BITS 4u
-#define POOL_RAY_LDS_WORDS (COOP_RAY_WORDS * 64u)
 #endif
+#define POOL_QCAP (64u * POOL_PIECE)   // ... and the queue ring holds exactly one such call: 256 entries
+#define POOL_RA(RAYS, LANE) ((RAYS)[(LANE)])
+#define POOL_RB(RAYS, LANE) ((RAYS)[64u + (LANE)])
+#define POOL_RAY_LDS_WORDS (64u * 8u)
 static_assert(POOL_QCAP >= 64u * POOL_PIECE && (POOL_QCAP & (POOL_QCAP - 1u)) == 0u, "queue ring too small for one enqueue");
 __host__ __device__ inline uint32_t pool_fixed_words() { return 64u + POOL_QCAP + POOL_RAY_LDS_WORDS + 128u; }
 __host__ __device__ inline uint32_t pool_cap(uint32_t topNeed, uint32_t blasNeed)
@@ -70,16 +69,17 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
     return topNeed * 64u + pool_cap(topNeed, blasNeed) + pool_fixed_words();
 }
 
-#define POOL_LANE_SHIFT 26u            // pool item = owning lane << 26 | (POOL_RAYS_LDS: instance parity << 25 |) wide-node index
-#if POOL_RAYS_LDS
-#define POOL_NODE_MASK ((1u << POOL_SLOT_SHIFT) - 1u)
-#else
+#define POOL_LANE_SHIFT 26u            // pool item = owning lane << 26 | wide-node index
 #define POOL_NODE_MASK ((1u << POOL_LANE_SHIFT) - 1u)
-#endif
 static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rule (derive_accel) must match the pool item layout");
 #define POOL_INBLAS 0xfffffffeu        // top-level cursor of a lane whose instance is in the pool
 #ifndef POOL_TEST_MIN
-#define POOL_TEST_MIN 48u              // queued triangle tests a test step waits for (32-64: flat within 1.5 %; 96-128: +2-5 %)
+#define POOL_TEST_MIN 32u              // queued triangle tests a test step waits for (at 6 waves / SIMD: 32 -> 48 -> 64: +1 %, +2 % frame time)
+#endif
+// POOL_REPEAT: pool steps run back to back (while the pool holds a full batch) before the lane states are looked at again --
+// the step selection at the top of the loop is a third of a step's scalar instructions.
+#ifndef POOL_REPEAT
+#define POOL_REPEAT 1u
 #endif
 #ifndef POOL_W_TOP
 #define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
@@ -91,11 +91,10 @@ static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rul
 #define POOL_MAX_ITER (1u << 24)       // iterations of one wave before it gives up (a full 1080p frame needs ~1e5 per wave)
 #endif
 #ifndef POOL_IDLE_MIN
-#define POOL_IDLE_MIN 32               // finished / free lanes a hand-over step waits for (16: +13 %, 24: +4 %, 40-48: +0-3 % frame time)
+#define POOL_IDLE_MIN 40               // finished / free lanes a hand-over step waits for (at 6 waves / SIMD: 24: +5 %, 32: +1-2 % frame time)
 #endif
 
 
-#if POOL_RAYS_LDS
 // one test step: up to 64 queued (ray slot, triangle) pairs, one per lane; the ray comes from the entry's LDS slot
 __device__ __forceinline__ void pool_test_step(const AccelView& A, const uint32_t* queue, const float4* rays, unsigned long long* best,
                                                uint32_t lane, uint32_t& qHead, uint32_t qTail, float tmin, float tmax)
@@ -107,8 +106,7 @@ __device__ __forceinline__ void pool_test_step(const AccelView& A, const uint32_
     const uint32_t e = lane < n ? queue[(qHead + lane) & (POOL_QCAP - 1u)] : (lane << COOP_LANE_SHIFT);
     const float4* tp = reinterpret_cast<const float4*>(A.tris + (e & COOP_SLOT_MASK));      // requested first (idle lanes read slot 0)
     const float4 tq0 = tp[0], tq1 = tp[1], tq2 = tp[2];
-    const float4* rs = rays + 2u * (e >> COOP_PAR_SHIFT);
-    const float4 ra = rs[0], rb = rs[1];
+    const float4 ra = POOL_RA(rays, e >> COOP_LANE_SHIFT), rb = POOL_RB(rays, e >> COOP_LANE_SHIFT);
     if (lane < n) {
         float t, b1, b2;
         if (coop_triangle_regs(tq0, tq1, tq2, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), tmin, tmax, t, b1, b2)) {
@@ -136,7 +134,6 @@ __device__ __forceinline__ void pool_enqueue(const AccelView& A, uint32_t* queue
     for (uint32_t k = 0; k < cnt; ++k) queue[(at + k) & (POOL_QCAP - 1u)] = tagBits | (start + k);
     qTail += total;
 }
-#endif
 
 // INL: the scene has instances whose BLAS is a single leaf of <= 8 triangles; they are handled inside the top-level step
 // (below).  A separate instantiation, chosen by the host per scene: the kernel sits at its register budget, and the extra
@@ -160,14 +157,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     L.ray = reinterpret_cast<float*>(L.queue + POOL_QCAP);
     L.best = reinterpret_cast<unsigned long long*>(L.ray + POOL_RAY_LDS_WORDS);
     L.pend = nullptr;
-#if POOL_RAYS_LDS
     float4* rays = reinterpret_cast<float4*>(L.ray);       // [lane * 2 + parity][2]
 #define POOL_TEST() pool_test_step(A, L.queue, rays, L.best, lane, qHead, qTail, tmin, tmax)
 #define POOL_ENQ(TAG, CNT, START) pool_enqueue(A, L.queue, rays, L.best, lane, TAG, CNT, START, qHead, qTail, tmin, tmax)
-#else
-#define POOL_TEST() coop_test_step(A, L, lane, qHead, qTail, tmin, tmax, R, par, w6)
-#define POOL_ENQ(TAG, CNT, START) coop_enqueue(A, L, lane, TAG, CNT, START, qHead, qTail, tmin, tmax, R, par, w6)
-#endif
     pendN[lane] = 0u;
 
     const uint32_t nWavesGrid = gridDim.x * (blockDim.x >> 6);
@@ -179,18 +171,10 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     uint32_t resBase = 0, resEnd = 0;
     uint32_t rayIdx = COOP_NONE;
     uint32_t tcur = COOP_NONE, tsp = 0;                    // top-level cursor / stack pointer
-    uint32_t par = 0;
-#if !POOL_RAYS_LDS
-    uint32_t w6 = lane << COOP_OWNER_SHIFT;
-#endif
     uint32_t markPrev = 0, finMark = 0;
     bool finishing = false, anyHit = (REC == 2);
     typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
-#if !POOL_RAYS_LDS
-    RayInst R;
-    R.o = o; R.d = d; R.rcp = mk3(0.f, 0.f, 0.f); R.exactOnly = true;
-#endif
 
     // Flat top level (A.topFlat != 0): the instances a ray still has to enter are a per-lane BITMAP over the instance slots in
     // LDS (A.topNeed = ceil(instances / 32) words per lane) plus their count in a register, instead of a stack of mask
@@ -217,7 +201,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     } while (0)
 #define POOL_START_RAY(WALK) do {                                                                      \
         L.best[lane] = ~0ull;                                                                          \
-        tsp = 0; par = 0; markPrev = qHead; finishing = false;                                         \
+        tsp = 0; markPrev = qHead; finishing = false;                                         \
         tcur = (WALK) ? (TAG_TLAS | 0u) : COOP_NONE;                                                   \
     } while (0)
 
@@ -229,16 +213,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // as traverse_coop.h; kind 6 = pool step
     uint32_t stState[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#ifdef POOL_WATCHDOG_V1
-    uint32_t iter = 0;
-    for (;;) {
-        iter = __builtin_amdgcn_readfirstlane(iter + 1u);
-        if (iter > POOL_MAX_ITER) break;
-#else
     for (uint32_t iter = 0; iter < POOL_MAX_ITER; ++iter) {
-#endif
         // a lane whose instance has left the pool moves on along its top-level stack
-        if (tcur == POOL_INBLAS && pendN[lane] == 0u) POOL_TPOP();
+        if (tcur == POOL_INBLAS && pendN[lane] == 0u) { POOL_TPOP(); markPrev = qTail; }       // the tests of the instance just left
         if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }
         const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
         const bool isFree = (rayIdx == COOP_NONE);
@@ -451,11 +428,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 *reinterpret_cast<float4*>(m + 4) = ip[1];
                 *reinterpret_cast<float4*>(m + 8) = ip[2];
                 *reinterpret_cast<float4*>(m + 12) = ip[3];
-#if POOL_RAYS_LDS
-                // the ray in the instance's space goes into this lane's OTHER slot: the slot of the instance being left keeps
-                // serving its queued tests, and the tests that used the other slot (the instance before that) are done (`ready`)
+                // the ray in the instance's space goes into this lane's slot: the queued tests of the instance left before are
+                // done (`ready`)
                 RayInst R;
-                par ^= 1u;
                 R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
                 R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
                 R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
@@ -463,30 +438,10 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
                 R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
                 {
-                    float4* rs = rays + 2u * (lane * 2u + par);
-                    rs[0] = make_float4(R.o.x, R.o.y, R.o.z, __uint_as_float(ci));
-                    rs[1] = make_float4(R.d.x, R.d.y, R.d.z, __uint_as_float((R.exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)));
+                    POOL_RA(rays, lane) = make_float4(R.o.x, R.o.y, R.o.z, __uint_as_float(ci));
+                    POOL_RB(rays, lane) = make_float4(R.d.x, R.d.y, R.d.z, __uint_as_float((R.exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)));
                 }
-#else
-                {   // park the ray of the instance being left: queued tests of it may still be pending
-                    float* rs = L.ray + lane;
-                    rs[0 * 64] = R.o.x; rs[1 * 64] = R.o.y; rs[2 * 64] = R.o.z;
-                    rs[3 * 64] = R.d.x; rs[4 * 64] = R.d.y; rs[5 * 64] = R.d.z;
-                    rs[6 * 64] = __uint_as_float(w6);
-                }
-                w6 = (w6 & ~((1u << COOP_OWNER_SHIFT) - 1u)) | ci;
-                R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
-                R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
-                R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
-                const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
-                const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
-                R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
-#endif
                 const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
-                markPrev = qTail;            // everything queued so far belongs to instances being left
-#if !POOL_RAYS_LDS
-                par ^= 1u;
-#endif
                 if (rdsc.y & WIDE_LEAF) {
                     cntE = rdsc.y & 0x7fffffffu; stE = rdsc.x;
                     POOL_TPOP();
@@ -506,23 +461,23 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             }
             {
                 const unsigned long long pm = __ballot(rootNode != COOP_NONE);
-#if POOL_RAYS_LDS
-                if (rootNode != COOP_NONE) pool[poolTop + lanes_below(pm)] = ((lane * 2u + par) << POOL_SLOT_SHIFT) | (rootNode & POOL_NODE_MASK);
-#else
                 if (rootNode != COOP_NONE) pool[poolTop + lanes_below(pm)] = (lane << POOL_LANE_SHIFT) | (rootNode & POOL_NODE_MASK);
-#endif
                 poolTop += (uint32_t)__popcll(pm);
             }
-            const uint32_t tagBits = (lane << COOP_LANE_SHIFT) | (par << COOP_PAR_SHIFT);
-            while (__any(cntE != 0u)) {      // (a leaf of more than 8 triangles goes in pieces)
+            const uint32_t tagBits = lane << COOP_LANE_SHIFT;
+            const bool leafRoot = cntE != 0u;
+            while (__any(cntE != 0u)) {      // (a leaf of more than POOL_PIECE triangles goes in pieces)
                 const uint32_t c = min(cntE, POOL_PIECE);
                 POOL_ENQ(tagBits, c, stE);
                 stE += c; cntE -= c;
             }
+            if (leafRoot) markPrev = qTail;      // the slot serves these tests until they are done
             continue;
         }
         // ---- pool step: up to 64 pending BLAS nodes, whichever rays they belong to -----------------------------------
         if (poolTop != 0u) {
+          uint32_t rep = 0;
+          do {
             const uint32_t freeE = PCAP - poolTop;
             const uint32_t npop = min(min(64u, poolTop), freeE > RESERVE ? freeE - RESERVE : 1u);
             COOP_STAT(6, npop);
@@ -534,32 +489,14 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             // below instead of behind them
             const float4* wp = reinterpret_cast<const float4*>(A.wide + (item & POOL_NODE_MASK));
             const float4 l0 = wp[0], l1 = wp[1], r0 = wp[2], r1 = wp[3];
-#if POOL_RAYS_LDS
             // the object-space ray of the item, from its LDS slot
-            const uint32_t slotBits = item & ~POOL_NODE_MASK;
-            const float4* rs = rays + 2u * (item >> POOL_SLOT_SHIFT);
-            const float4 ra = rs[0], rb = rs[1];
+            const uint32_t slotBits = wl << POOL_LANE_SHIFT;
+            const float4 ra = POOL_RA(rays, wl), rb = POOL_RB(rays, wl);
             const uint32_t qf = __float_as_uint(rb.w);
             RayInst Q;
             Q.o = mk3(ra.x, ra.y, ra.z);
             Q.d = mk3(rb.x, rb.y, rb.z);
             Q.rcp = mk3(__builtin_amdgcn_rcpf(Q.d.x), __builtin_amdgcn_rcpf(Q.d.y), __builtin_amdgcn_rcpf(Q.d.z));
-#else
-            const uint32_t slotBits = wl << POOL_LANE_SHIFT;
-            // the object-space ray of the item's owner, from its registers
-            const uint32_t myFlags = (R.exactOnly ? 1u : 0u) | (par << 1) | (anyHit ? 4u : 0u);
-            const uint32_t qf = __shfl(myFlags, wl);
-            RayInst Q;
-            Q.o = mk3(__shfl(R.o.x, wl), __shfl(R.o.y, wl), __shfl(R.o.z, wl));
-            Q.d = mk3(__shfl(R.d.x, wl), __shfl(R.d.y, wl), __shfl(R.d.z, wl));
-#ifdef POOL_RCP_SHUFFLE
-            Q.rcp = mk3(__shfl(R.rcp.x, wl), __shfl(R.rcp.y, wl), __shfl(R.rcp.z, wl));
-#else
-            // 1/d recomputed from the shuffled direction (three v_rcp_f32, the same values the owner computed) instead of
-            // three more lane shuffles: the VALU has slots to spare, the LDS crossbar is on the critical path
-            Q.rcp = mk3(__builtin_amdgcn_rcpf(Q.d.x), __builtin_amdgcn_rcpf(Q.d.y), __builtin_amdgcn_rcpf(Q.d.z));
-#endif
-#endif
             Q.exactOnly = (qf & 1u) != 0u;
             uint32_t cntL = 0, stL = 0, cntR = 0, stR = 0, pushL = COOP_NONE, pushR = COOP_NONE;
             int delta = 0;
@@ -600,11 +537,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 poolTop += nR + (uint32_t)__popcll(mL);
             }
             if (valid && delta != 0) atomicAdd(&pendN[wl], (uint32_t)delta);
-#if POOL_RAYS_LDS
             const uint32_t tagBits = slotBits;
-#else
-            const uint32_t tagBits = (wl << COOP_LANE_SHIFT) | (((qf >> 1) & 1u) << COOP_PAR_SHIFT);
-#endif
             while (__any((cntL | cntR) != 0u)) {
                 const uint32_t cl = min(cntL, POOL_PIECE), cr = min(cntR, POOL_PIECE);
                 POOL_ENQ(tagBits, cl, stL);
@@ -612,6 +545,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 stL += cl; cntL -= cl; stR += cr; cntR -= cr;
             }
             if (qTail - qHead >= POOL_TEST_MIN) POOL_TEST();
+          } while (++rep < POOL_REPEAT && poolTop >= 64u);
             continue;
         }
         // (not reached: with an empty pool one of the two top-level branches above is always taken)
