@@ -236,6 +236,36 @@ __device__ __forceinline__ bool leaf_box_maybe(const RayInst& R, f3 bmin, f3 bma
     return !(n0 - tFar > m) && !(n0 > cullT);
 }
 
+// One child of a wide node in the culled walk, leaf or inner, in one straight-line evaluation of the slabs (the two kinds
+// differ in the margin and in what "undecided" means, not in the arithmetic -- and a wave's 64 items are a mix of both):
+//   leaf  -> leaf_box_maybe(R, bmin, bmax, cullT)
+//   inner -> slab_fast_t(R, bmin, bmax, tn) && !(tn > cullT)
+// with exactly their decisions; tn is the entry distance (inner children only).
+__device__ __forceinline__ bool cull_child(const RayInst& R, f3 bmin, f3 bmax, bool isLeaf, float cullT, float& tn)
+{
+    const f3 tA = (bmin - R.o) * R.rcp, tB = (bmax - R.o) * R.rcp;
+    const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
+    const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
+    const float n0 = fmaxf(tNear, 0.0f);
+    const float m = (isLeaf ? RDX_CULL_M : 4.8e-7f) * (fabsf(tFar) + n0) + 1e-30f;
+    const float diff = tFar - n0;
+    const bool hit = diff > m, miss = -diff > m;
+    bool res = isLeaf ? !miss : hit;
+    tn = n0;
+    if (!isLeaf && (R.exactOnly || !(hit || miss))) {
+        // inside the band, or a (nearly) zero direction component: the reference's own form decides (radiance.cl:195-208)
+        const f3 dA = (bmin - R.o) / R.d, dB = (bmax - R.o) / R.d;
+        const f3 t1 = mk3(cl_min(dA.x, dB.x), cl_min(dA.y, dB.y), cl_min(dA.z, dB.z));
+        const f3 t2 = mk3(cl_max(dA.x, dB.x), cl_max(dA.y, dB.y), cl_max(dA.z, dB.z));
+        const float eNear = cl_max(cl_max(t1.x, t1.y), t1.z);
+        const float eFar = cl_min(cl_min(t2.x, t2.y), t2.z);
+        tn = cl_max(eNear, 0.0f);
+        res = eFar > tn;
+    }
+    if (isLeaf && R.exactOnly) return true;
+    return res && !(tn > cullT);
+}
+
 struct Best {
     float t, b1, b2;
     uint32_t slot, inst;

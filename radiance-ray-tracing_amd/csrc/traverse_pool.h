@@ -77,9 +77,11 @@ static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rul
 #define POOL_TEST_MIN 32u              // queued triangle tests a test step waits for (at 6 waves / SIMD: 32 -> 48 -> 64: +1 %, +2 % frame time)
 #endif
 // POOL_REPEAT: pool steps run back to back (while the pool holds a full batch) before the lane states are looked at again --
-// the step selection at the top of the loop is a third of a step's scalar instructions.
+// the step selection at the top of the loop is a good part of a step's scalar instructions.  1080p frame, sample1 /
+// Sponza-class / 10.4 M triangles: 1 -> 13.62 / 27.64 / 72.06 ms, 2 -> 13.52 / 27.34 / 70.92, 3 -> 13.51 / 27.23 / 70.21,
+// 4 -> 13.48 / 27.15 / 70.36.
 #ifndef POOL_REPEAT
-#define POOL_REPEAT 1u
+#define POOL_REPEAT 3u
 #endif
 #ifndef POOL_W_TOP
 #define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
@@ -167,7 +169,8 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     uint32_t chunk = min(chunkMax, max(64u, (n / (4u * nWavesGrid)) & ~63u));
 
     uint32_t qHead = 0, qTail = 0, poolTop = 0;            // wave-uniform
-    bool exhausted = false, lastOfAll = false;
+    bool exhausted = false;
+    bool lastOfAll = false;
     uint32_t resBase = 0, resEnd = 0;
     uint32_t rayIdx = COOP_NONE;
     uint32_t tcur = COOP_NONE, tsp = 0;                    // top-level cursor / stack pointer
@@ -511,12 +514,13 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                         float cullT = tmax * RDX_CULL_K;
                         if (((REC == 1) || !(qf & 4u)) && hb != 0xffffffffu) cullT = fminf(cullT, __uint_as_float(hb) * RDX_CULL_K);
                         float tnL = 0.f, tnR = 0.f;
-                        if (ld1 & WIDE_LEAF) {
-                            if (leaf_box_maybe(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), cullT)) { cntL = ld1 & 0x7fffffffu; stL = ld0; }
-                        } else if (slab_fast_t(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), tnL) && !(tnL > cullT)) pushL = ld0;
-                        if (rd1 & WIDE_LEAF) {
-                            if (leaf_box_maybe(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), cullT)) { cntR = rd1 & 0x7fffffffu; stR = rd0; }
-                        } else if (slab_fast_t(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), tnR) && !(tnR > cullT)) pushR = rd0;
+                        const bool leafL = (ld1 & WIDE_LEAF) != 0u, leafR = (rd1 & WIDE_LEAF) != 0u;
+                        if (cull_child(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), leafL, cullT, tnL)) {
+                            if (leafL) { cntL = ld1 & 0x7fffffffu; stL = ld0; } else pushL = ld0;
+                        }
+                        if (cull_child(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), leafR, cullT, tnR)) {
+                            if (leafR) { cntR = rd1 & 0x7fffffffu; stR = rd0; } else pushR = rd0;
+                        }
                         // the nearer child goes on top of the LIFO (the "L" slot is written above the "R" slot below)
                         if (pushL != COOP_NONE && pushR != COOP_NONE && tnL > tnR) { const uint32_t t_ = pushL; pushL = pushR; pushR = t_; }
                     } else {
