@@ -21,6 +21,7 @@ struct AccelView {                 // derived traversal layout (see rdx_types.h)
     uint32_t topNeed, blasNeed;    // its top-level / per-BLAS parts (pool engine: private top-level stacks + shared node pool)
     uint32_t leafRoots;            // pool engine: the scene has single-leaf BLASes handled in the flat top-level step (needs topFlat)
     uint32_t topFlat;              // pool engine: > 0 = number of top-level nodes, evaluated all at once per ray (<= 64 nodes)
+    uint32_t numInsts;             // instances in `insts`
     uint32_t* status;              // device-visible status word (pinned host memory): bit 0 = a traversal wave hit its iteration bound
     uint32_t cull;                 // pool engine: culled walk (best-t culling of closest-hit rays, leaf-box test; kernels.hip)
     uint32_t kernel;               // 2 = wave-cooperative (default), 3 = wave-cooperative with a shared node pool, 1 = per-lane wide, 0 = reference order

@@ -1532,12 +1532,14 @@ void launch_pcg3d_batch(hipStream_t st, const uint32_t* in3, float* out3, uint32
 
 #ifdef COOP_STATS
 // experiment builds only (RDX_DEFINES=-DCOOP_STATS): read and clear the step statistics of traverse_coop.h
-extern "C" int rdx_debug_coop_stats(unsigned long long* out24)     // [0,16) step statistics, [16,24) lane states
+extern "C" int rdx_debug_coop_stats(unsigned long long* out24)     // [0,16) step statistics, [16,24) lane states, [24,32) cycles per step kind
 {
     if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_coop_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out24 + 16, HIP_SYMBOL(g_coop_state), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out24 + 24, HIP_SYMBOL(g_coop_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[16] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_state), z, 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_cycles), z, 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stats), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif

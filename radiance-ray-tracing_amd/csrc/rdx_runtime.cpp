@@ -51,6 +51,7 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     bool sbtOffsets = false;               // an instance has SBTOffset != 0: reference-order kernel only
     uint32_t nWide = 0;                    // inner BLAS nodes of the scene (sizes the automatic choice of the culled walk)
     uint32_t blasNeedAny = 0;              // BLAS stack need of the pool engine when the push order depends on the ray (culled walk)
+    uint32_t nInst = 0;
     uint32_t topFlat = 0, topFlatNeed = 1; // pool engine: number of top-level nodes if they are few enough (<= 64) to be evaluated
                                         // all at once per ray instead of walked, and the instance-mask entries that can then pile up
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
@@ -437,6 +438,7 @@ int derive_accel(rdx_buffer_s* tb)
                 if ((di.rootDesc1 & WIDE_LEAF) && (di.rootDesc1 & 0x7fffffffu) <= 8u) { dT[i].w3 = 1; ac->leafRoots = true; }
             }
         }
+        ac->nInst = nInst;
         ac->topFlatNeed = std::max(1u, (nInst + 31u) / 32u);       // words per lane of the pending-instance bitmap
         (void)masks;
     }
@@ -487,6 +489,7 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.cull = (v.kernel == 3 && (g.cull > 0 || (g.cull < 0 && acc(tb)->nWide >= 16384u))) ? 1u : 0u;
     v.topNeed = acc(tb)->topNeed; v.blasNeed = v.cull ? acc(tb)->blasNeedAny : acc(tb)->blasNeed;
     v.topFlat = g.topFlat ? acc(tb)->topFlat : 0u;
+    v.numInsts = acc(tb)->nInst;
     if (v.topFlat) v.topNeed = acc(tb)->topFlatNeed;          // flat top level: words per lane of the pending-instance bitmap
     v.leafRoots = (v.topFlat && g.inlineLeafRoots && acc(tb)->leafRoots) ? 1u : 0u;
     return v;

@@ -125,7 +125,8 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
 #ifdef COOP_STATS
 __device__ unsigned long long g_coop_stats[16];
 __device__ unsigned long long g_coop_state[8];      // lane-iterations spent in: node, top, inst, leaf, finishing, done, free, iterations*64
-#define COOP_STAT(kind, lanes) do { statN[kind] += 1u; statL[kind] += (uint32_t)(lanes); } while (0)
+__device__ unsigned long long g_coop_cycles[8];     // pool engine: wave cycles (s_memtime) per step kind; a test that follows a pool step counts as 6
+#define COOP_STAT(kind, lanes) do { statN[kind] += 1u; statL[kind] += (uint32_t)(lanes); statKind = (kind); } while (0)
 #else
 #define COOP_STAT(kind, lanes) do {} while (0)
 #endif
@@ -288,7 +289,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
     const uint32_t quota = COOP_STEAL ? min(64u, max((uint32_t)COOP_MIN_QUOTA, (n + nWavesGrid - 1u) / nWavesGrid)) : 64u;
 
 #ifdef COOP_STATS
-    uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // wave-uniform
+    uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statKind = 7u;      // wave-uniform
     uint32_t stState[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     uint32_t qHead = 0, qTail = 0;                         // wave-uniform, monotonically increasing

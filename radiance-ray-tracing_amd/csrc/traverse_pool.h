@@ -83,6 +83,12 @@ static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rul
 #ifndef POOL_REPEAT
 #define POOL_REPEAT 3u
 #endif
+#ifndef POOL_TOP_READLANE
+#define POOL_TOP_READLANE 1
+#endif
+#ifndef POOL_CHAIN_INST
+#define POOL_CHAIN_INST 1
+#endif
 #ifndef POOL_W_TOP
 #define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
 #endif
@@ -213,10 +219,14 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     // (rdx_trace_rays then returns an error) instead of hanging the GPU.  One scalar add + compare per iteration.
     bool finished = false;
 #ifdef COOP_STATS
-    uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // as traverse_coop.h; kind 6 = pool step
+    uint32_t statN[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statL[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statKind = 7u;      // as traverse_coop.h; kind 6 = pool step
+    unsigned long long statC[8] = {0, 0, 0, 0, 0, 0, 0, 0}, statT = __builtin_readcyclecounter();
     uint32_t stState[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (uint32_t iter = 0; iter < POOL_MAX_ITER; ++iter) {
+#ifdef COOP_STATS
+        { const unsigned long long now_ = __builtin_readcyclecounter(); statC[statKind] += now_ - statT; statT = now_; statKind = 7u; }
+#endif
         // a lane whose instance has left the pool moves on along its top-level stack
         if (tcur == POOL_INBLAS && pendN[lane] == 0u) { POOL_TPOP(); markPrev = qTail; }       // the tests of the instance just left
         if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }
@@ -225,8 +235,11 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
         const bool has = (tcur != COOP_NONE) && (tcur != POOL_INBLAS);
         const uint32_t tag = tcur & TAG_MASK;
-        const bool isTop = has && tag == TAG_TLAS, isInst = has && tag == TAG_INST;
-        const int nTop = __popcll(__ballot(isTop)), nInst = __popcll(__ballot(isInst));
+        const bool isTop = has && tag == TAG_TLAS;
+        bool isInst = has && tag == TAG_INST;
+        const int nTop = __popcll(__ballot(isTop));
+        int nInst = __popcll(__ballot(isInst));
+        bool chainInst = false;          // the top-level step hands its rays straight to an instance step (POOL_CHAIN_INST)
         const int nPool = (int)min(64u, poolTop);
         const bool workAny = (nTop | nInst) != 0 || poolTop != 0u;
         const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
@@ -306,7 +319,99 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
             COOP_STAT(4, nTop);
             if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) POOL_DROP(); }
-            if (A.topFlat != 0u) {
+#if POOL_TOP_READLANE
+            if (!INL && A.topFlat != 0u) {
+                // Small top-level tree (<= 64 nodes): no walk.  Every node is looked at once, in index order (parents come
+                // before their children, DFS pre-order), by all lanes of the step together.  `reach` says which nodes the
+                // reference's walk arrives at: the root, and the children of every reached inner node whose box the ray
+                // hits (same decision rule); reached leaves file their instances (after the pre-test) in the lane's bitmap.
+                // Same visit set, 1 step instead of one per visited node.
+                // The node records come in with ONE vector load -- lane i holds node i -- and likewise the pre-test boxes of
+                // 64 instances at a time; the loop broadcasts them with v_readlane.  (Until round 2 every node and instance
+                // was a scalar load the loop then waited for: the step cost 4.8 pool steps, a sixth of the Sponza-class
+                // frame's traversal cycles and more than a quarter of sample1's, tools/coop_stats.py.)
+                const float4* npv = reinterpret_cast<const float4*>(A.tnodes + min(lane, A.topFlat - 1u));
+                const float4 vb0 = npv[0], vb1 = npv[1];
+                const uint4 vw = *reinterpret_cast<const uint4*>(npv + 2);
+                uint32_t ibase = 0;                              // the 64 instances whose boxes the lanes hold
+                float4 vmin = make_float4(0.f, 0.f, 0.f, -1.f), vmax = vmin;
+                if (A.numInsts != 0u) {
+                    vmin = *reinterpret_cast<const float4*>(A.insts[min(lane, A.numInsts - 1u)].worldMin);
+                    vmax = *reinterpret_cast<const float4*>(A.insts[min(lane, A.numInsts - 1u)].worldMax);
+                }
+#define POOL_RLF(V, L) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), (int)(L)))
+#define POOL_RLU(V, L) ((uint32_t)__builtin_amdgcn_readlane((int)(V), (int)(L)))
+                const bool mine = isTop && tcur != COOP_NONE;
+                RayInst W;
+                W.o = o; W.d = d;
+                W.rcp = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                const float amin_ = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+                const float amax_ = fmaxf(fmaxf(fabsf(W.rcp.x), fabsf(W.rcp.y)), fabsf(W.rcp.z));
+                W.exactOnly = !(amin_ > 1e-20f) || !(amax_ < 1e20f);
+                const float oMax = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
+                const bool preOK = !W.exactOnly && (oMax < 1e20f);
+                unsigned long long reach = mine ? 1ull : 0ull;
+                for (uint32_t i = 0; i < A.topFlat; ++i) {
+                    const uint32_t wx = POOL_RLU(vw.x, i), wy = POOL_RLU(vw.y, i), wz = POOL_RLU(vw.z, i);
+                    const bool r = ((reach >> i) & 1ull) != 0ull;
+                    if (__ballot(r) == 0ull) continue;          // no ray of the step gets here
+                    if (!(wx & LEAF_BIT)) {
+                        const f3 bmin = mk3(POOL_RLF(vb0.x, i), POOL_RLF(vb0.y, i), POOL_RLF(vb0.z, i));
+                        const f3 bmax = mk3(POOL_RLF(vb1.x, i), POOL_RLF(vb1.y, i), POOL_RLF(vb1.z, i));
+                        if (r && slab_fast(W, bmin, bmax)) reach |= (1ull << wx) | (1ull << wy);
+                    } else if (wz == TYPE_INST) {
+                        const uint32_t count = wx & 0x7fffffffu;
+                        for (uint32_t b0 = 0; b0 < count; b0 += 16u) {
+                            uint32_t m16 = 0;
+                            for (uint32_t k = 0; k < min(16u, count - b0); ++k) {
+                                const uint32_t ci = wy + b0 + k;              // the same instance for every lane here
+                                if (ci - ibase >= 64u) {                      // (scenes of more than 64 instances: the next 64 boxes)
+                                    ibase = ci & ~63u;
+                                    const uint32_t li = min(ibase + lane, A.numInsts - 1u);
+                                    vmin = *reinterpret_cast<const float4*>(A.insts[li].worldMin);
+                                    vmax = *reinterpret_cast<const float4*>(A.insts[li].worldMax);
+                                }
+                                const uint32_t il = ci - ibase;
+#if POOL_TOP_READLANE == 2
+                                const bool enter = coop_inst_pretest(A.insts[ci], o, W.rcp, oMax, preOK);
+#else
+                                // conservative world-space pre-test (coop_inst_pretest), the instance's boxes broadcast from lane `il`
+                                const float wc = POOL_RLF(vmin.w, il);
+                                bool enter = true;
+                                if (preOK && wc >= 0.0f) {
+                                    const float m = wc * (oMax + POOL_RLF(vmax.w, il));
+                                    const f3 tA = (mk3(POOL_RLF(vmin.x, il) - m, POOL_RLF(vmin.y, il) - m, POOL_RLF(vmin.z, il) - m) - o) * W.rcp;
+                                    const f3 tB = (mk3(POOL_RLF(vmax.x, il) + m, POOL_RLF(vmax.y, il) + m, POOL_RLF(vmax.z, il) + m) - o) * W.rcp;
+                                    const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
+                                    const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
+                                    const float n0 = fmaxf(tNear, 0.0f);
+                                    const float band = 4.8e-7f * (fabsf(tFar) + n0) + 1e-30f;
+                                    enter = !((tFar - n0) < -band);
+                                }
+#endif
+                                if (enter) m16 |= 1u << k;
+                            }
+                            if (r && m16) POOL_FILE_INSTANCES(m16, wy + b0);
+                        }
+                    }
+                }
+                if (mine) POOL_TPOP();
+#undef POOL_RLF
+#undef POOL_RLU
+#if POOL_CHAIN_INST
+                // the rays that found instances enter their first one right away, together with the lanes already waiting for an
+                // instance step: one step that serves ~48 lanes instead of two that serve ~40 and ~23
+                isInst = (tcur != COOP_NONE) && (tcur != POOL_INBLAS) && (tcur & TAG_MASK) == TAG_INST;
+                nInst = __popcll(__ballot(isInst));
+                chainInst = nInst > 0 && PCAP - poolTop >= 64u + RESERVE;
+                if (!chainInst) continue;
+                goto pool_instance_step;
+#else
+                continue;
+#endif
+            }
+#endif
+            if (A.topFlat != 0u) {       // (INL: scenes with single-leaf instances, handled on the spot; node and instance records as scalar loads)
                 // Small top-level tree (<= 64 nodes): no walk.  Every node is looked at once, in index order (parents come
                 // before their children, DFS pre-order), by all lanes of the step together -- the node is the same for all
                 // of them, so its box comes through scalar loads and nothing is fetched along a dependent chain.  `reach`
@@ -372,6 +477,12 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                     }
                     POOL_TPOP();
                 }
+#if POOL_CHAIN_INST
+                isInst = (tcur != COOP_NONE) && (tcur != POOL_INBLAS) && (tcur & TAG_MASK) == TAG_INST;
+                nInst = __popcll(__ballot(isInst));
+                chainInst = nInst > 0 && PCAP - poolTop >= 64u + RESERVE;
+                if (chainInst) goto pool_instance_step;
+#endif
                 continue;
             }
             if (isTop && tcur != COOP_NONE) {
@@ -405,7 +516,10 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             continue;
         }
         // ---- instance entry (radiance.cl:161-169): the BLAS root goes into the pool ----------------------------------
-        if (nInst > 0 && nInst * POOL_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE) {
+#if POOL_CHAIN_INST
+    pool_instance_step:
+#endif
+        if (chainInst || (nInst > 0 && nInst * POOL_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE)) {
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
             if (__ballot(ready) == 0ull) { POOL_TEST(); continue; }
             COOP_STAT(5, __popcll(__ballot(ready)));
@@ -558,6 +672,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     if (!finished && lane == 0 && A.status) atomicOr(A.status, 1u);       // the iteration bound was hit: the host reports an error
 #ifdef COOP_STATS
     if (lane < 8u) atomicAdd(&g_coop_state[lane], (unsigned long long)stState[lane]);
+    if (lane < 8u) atomicAdd(&g_coop_cycles[lane], statC[lane]);
     if (lane < 7u) { atomicAdd(&g_coop_stats[lane], (unsigned long long)statN[lane]); atomicAdd(&g_coop_stats[8u + lane], (unsigned long long)statL[lane]); }
 #endif
     pol.retire(st);

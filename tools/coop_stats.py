@@ -18,7 +18,7 @@ for cfg, w, h in (("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_co
     s = scenes.CONFIGS[cfg](w, h, 4, 8)
     dev = scenes.DeviceScene(s)
     dev.render()
-    out = (ctypes.c_ulonglong * 24)()
+    out = (ctypes.c_ulonglong * 32)()
     fn(out)                                   # clear what the warm-up frame counted
     dev.set_rtprop(totalSamples=0); dev.render()
     st = rd.GetTraceStats()
@@ -30,6 +30,10 @@ for cfg, w, h in (("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_co
     names = ["node (pool engine: instance in the pool)", "top", "instance", "leaf", "finishing (tests pending)", "done (waits for hand-over)", "free"]
     print("  lane states per iteration: " + ", ".join("%s %.1f" % (names[k], 64 * stt[k] / stt[7]) for k in range(7))
           + ", other %.1f" % (64 - 64 * stt[:7].sum() / stt[7]))
+    cyc = np.array(out[24:32], np.float64)
+    if cyc.sum():
+        print("  wave cycles by step kind (a test that follows a pool step counts with it; 'test' = the rest): "
+              + ", ".join("%s %.1f %% (%.0f cycles / step)" % (KINDS[k], 100 * cyc[k] / cyc.sum(), cyc[k] / max(n[k], 1)) for k in range(8) if cyc[k]))
     for k in range(8):
         if n[k]:
             print("  %-14s %5.1f %% of steps, %5.1f lanes / step, %6.2f lane-steps per ray" % (KINDS[k], 100 * n[k] / n.sum(), l[k] / n[k], l[k] / rays))

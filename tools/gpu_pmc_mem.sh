@@ -5,8 +5,8 @@ WL=${1:-sponza}
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/mem_$WL; mkdir -p $OUT; cd /tmp
 B="python3 $R/bench.py --workload $WL --also= --no-cpu-baseline --no-pmc --no-reference --steps 2 --warmup 1"
 pass() { n=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$n -o r1 -- $B > $OUT/$n.log 2>&1 || echo "pass $n failed"; }
-pass a TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
-pass b TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum GRBM_GUI_ACTIVE
+# (the TA_* counters -- TA_TA_BUSY, TA_ADDR_STALLED_BY_TC_CYCLES, TA_*_WAVEFRONTS -- do not come back on this pool: rocprofv3 sat
+#  until the 300 s limit on both TA passes in round 2, so they are not collected)
 pass c TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum GRBM_GUI_ACTIVE
 pass d TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum GRBM_GUI_ACTIVE
 pass e TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum GRBM_GUI_ACTIVE
@@ -17,7 +17,7 @@ cd $R
 python3 - <<PY
 import sys, json; sys.path.insert(0, "tools")
 from prof_summary import per_kernel_all
-for n in "abcdefgh":
+for n in "cdefgh":
     d = per_kernel_all("$OUT/%s/r1_counter_collection.csv" % n)
     for k, v in d.items():
         if "fused_pool" in k: print(n, k, json.dumps({c: round(x) for c, x in v.items()}))
