@@ -35,10 +35,12 @@ using namespace rdx;
 // ------------------------------------------------------------------------------------------------
 constexpr int RDX_MAX_DEVICES = 16;
 // option "sort" -1: scenes with at least this many inner BVH nodes are sorted.  Measured (tools/gpu_sort_ab.sh, 1080p x 4 spp): the
-// sorted hand-out makes the traversal launches 10 % faster on the 262 k- and the 10.4 M-triangle scene (16 % slower on the 20 k one,
-// whose rays are coherent as they come), the sort itself costs 5-7 ms per frame (device-scope atomics of the counting sort) --
-// a net gain only where traversal is slow enough: 10.4 M triangles 106.7 -> 103.9 ms.
-constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 1u << 20;
+// sorted hand-out makes the traversal launches 7-10 % faster on the 262 k- and the 10.4 M-triangle scene (16 % slower on the 20 k
+// one, whose rays are coherent as they come), the sort itself costs 5-7 ms per frame (device-scope atomics of the counting sort).
+// That was a net gain on the 10.4 M-triangle scene while its frame took 107 ms (-> 103.9); with the r02c engine it no longer is
+// (59.2 ms unsorted, 61.0 sorted: the sort costs 7.2 ms and saves 5.6; Sponza-class 25.0 vs 29.0) -- so the automatic rule is OFF
+// for every scene size until the sort is cheaper (LDS radix sort); `sort` = 1 still forces it.
+constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 0xffffffffu;
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
     DNode* tnodes = nullptr; DNode* ctnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
