@@ -89,6 +89,9 @@ static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rul
 #ifndef POOL_CHAIN_INST
 #define POOL_CHAIN_INST 1
 #endif
+#ifndef POOL_ENQ_BOTH
+#define POOL_ENQ_BOTH 1
+#endif
 #ifndef POOL_W_TOP
 #define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
 #endif
@@ -119,7 +122,7 @@ __device__ __forceinline__ void pool_test_step(const AccelView& A, const uint32_
         float t, b1, b2;
         if (coop_triangle_regs(tq0, tq1, tq2, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), tmin, tmax, t, b1, b2)) {
             const uint32_t inst = __float_as_uint(ra.w);
-            const uint32_t low = (inst << COOP_INST_SHIFT) | ((e & COOP_SLOT_MASK) - A.insts[inst]._p0);      // BLAS-local triangle slot
+            const uint32_t low = (inst << COOP_INST_SHIFT) | ((e & COOP_SLOT_MASK) - (__float_as_uint(rb.w) & COOP_SLOT_MASK));      // BLAS-local triangle slot
             atomicMin(&best[e >> COOP_LANE_SHIFT], ((unsigned long long)__float_as_uint(t) << 32) | low);
         }
     }
@@ -140,6 +143,33 @@ __device__ __forceinline__ void pool_enqueue(const AccelView& A, uint32_t* queue
     while (qTail - qHead + total > POOL_QCAP) pool_test_step(A, queue, rays, best, lane, qHead, qTail, tmin, tmax);
     const uint32_t at = qTail + pre;
     for (uint32_t k = 0; k < cnt; ++k) queue[(at + k) & (POOL_QCAP - 1u)] = tagBits | (start + k);
+    qTail += total;
+}
+
+// the same for the two leaf children of a pool item at once: `ca` slots from `sa`, then `cb` slots from `sb` (ca, cb <= POOL_PIECE) --
+// one prefix sum over ca + cb instead of two
+__device__ __forceinline__ void pool_enqueue2(const AccelView& A, uint32_t* queue, const float4* rays, unsigned long long* best, uint32_t lane,
+                                              uint32_t tagBits, uint32_t ca, uint32_t sa, uint32_t cb, uint32_t sb, uint32_t& qHead,
+                                              uint32_t& qTail, float tmin, float tmax)
+{
+    const uint32_t cnt = ca + cb;
+    uint32_t pre = 0, total = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < POOL_PIECE_BITS + 1u; ++b) {
+        const unsigned long long m = __ballot((cnt >> b) & 1u);
+        pre += lanes_below(m) << b;
+        total += (uint32_t)__popcll(m) << b;
+    }
+    if (total == 0) return;
+    if (total > POOL_QCAP) {       // more than the ring holds (over half the lanes with two full leaves): one side at a time
+        pool_enqueue(A, queue, rays, best, lane, tagBits, ca, sa, qHead, qTail, tmin, tmax);
+        pool_enqueue(A, queue, rays, best, lane, tagBits, cb, sb, qHead, qTail, tmin, tmax);
+        return;
+    }
+    while (qTail - qHead + total > POOL_QCAP) pool_test_step(A, queue, rays, best, lane, qHead, qTail, tmin, tmax);
+    const uint32_t at = qTail + pre;
+    for (uint32_t k = 0; k < ca; ++k) queue[(at + k) & (POOL_QCAP - 1u)] = tagBits | (sa + k);
+    for (uint32_t k = 0; k < cb; ++k) queue[(at + ca + k) & (POOL_QCAP - 1u)] = tagBits | (sb + k);
     qTail += total;
 }
 
@@ -554,11 +584,11 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
                 const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
                 R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
-                {
-                    POOL_RA(rays, lane) = make_float4(R.o.x, R.o.y, R.o.z, __uint_as_float(ci));
-                    POOL_RB(rays, lane) = make_float4(R.d.x, R.d.y, R.d.z, __uint_as_float((R.exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)));
-                }
                 const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
+                {   // slot words 3 / 7: instance slot; first triangle slot of the instance (25 bits) | flags << 29 (bit 0 exactOnly, bit 2 anyHit)
+                    POOL_RA(rays, lane) = make_float4(R.o.x, R.o.y, R.o.z, __uint_as_float(ci));
+                    POOL_RB(rays, lane) = make_float4(R.d.x, R.d.y, R.d.z, __uint_as_float(rdsc.z | (((R.exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)) << 29)));
+                }
                 if (rdsc.y & WIDE_LEAF) {
                     cntE = rdsc.y & 0x7fffffffu; stE = rdsc.x;
                     POOL_TPOP();
@@ -609,7 +639,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             // the object-space ray of the item, from its LDS slot
             const uint32_t slotBits = wl << POOL_LANE_SHIFT;
             const float4 ra = POOL_RA(rays, wl), rb = POOL_RB(rays, wl);
-            const uint32_t qf = __float_as_uint(rb.w);
+            const uint32_t qf = __float_as_uint(rb.w) >> 29;
             RayInst Q;
             Q.o = mk3(ra.x, ra.y, ra.z);
             Q.d = mk3(rb.x, rb.y, rb.z);
@@ -658,8 +688,12 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             const uint32_t tagBits = slotBits;
             while (__any((cntL | cntR) != 0u)) {
                 const uint32_t cl = min(cntL, POOL_PIECE), cr = min(cntR, POOL_PIECE);
+#if POOL_ENQ_BOTH
+                pool_enqueue2(A, L.queue, rays, L.best, lane, tagBits, cl, stL, cr, stR, qHead, qTail, tmin, tmax);
+#else
                 POOL_ENQ(tagBits, cl, stL);
                 POOL_ENQ(tagBits, cr, stR);
+#endif
                 stL += cl; cntL -= cl; stR += cr; cntR -= cr;
             }
             if (qTail - qHead >= POOL_TEST_MIN) POOL_TEST();
