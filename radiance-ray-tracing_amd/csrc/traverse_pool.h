@@ -83,15 +83,6 @@ static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rul
 #ifndef POOL_REPEAT
 #define POOL_REPEAT 3u
 #endif
-#ifndef POOL_TOP_READLANE
-#define POOL_TOP_READLANE 1
-#endif
-#ifndef POOL_CHAIN_INST
-#define POOL_CHAIN_INST 1
-#endif
-#ifndef POOL_ENQ_BOTH
-#define POOL_ENQ_BOTH 1
-#endif
 #ifndef POOL_W_TOP
 #define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
 #endif
@@ -269,7 +260,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         bool isInst = has && tag == TAG_INST;
         const int nTop = __popcll(__ballot(isTop));
         int nInst = __popcll(__ballot(isInst));
-        bool chainInst = false;          // the top-level step hands its rays straight to an instance step (POOL_CHAIN_INST)
+        bool chainInst = false;          // the top-level step hands its rays straight to an instance step (below)
         const int nPool = (int)min(64u, poolTop);
         const bool workAny = (nTop | nInst) != 0 || poolTop != 0u;
         const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
@@ -349,7 +340,6 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
             COOP_STAT(4, nTop);
             if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) POOL_DROP(); }
-#if POOL_TOP_READLANE
             if (!INL && A.topFlat != 0u) {
                 // Small top-level tree (<= 64 nodes): no walk.  Every node is looked at once, in index order (parents come
                 // before their children, DFS pre-order), by all lanes of the step together.  `reach` says which nodes the
@@ -402,9 +392,6 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                                     vmax = *reinterpret_cast<const float4*>(A.insts[li].worldMax);
                                 }
                                 const uint32_t il = ci - ibase;
-#if POOL_TOP_READLANE == 2
-                                const bool enter = coop_inst_pretest(A.insts[ci], o, W.rcp, oMax, preOK);
-#else
                                 // conservative world-space pre-test (coop_inst_pretest), the instance's boxes broadcast from lane `il`
                                 const float wc = POOL_RLF(vmin.w, il);
                                 bool enter = true;
@@ -418,7 +405,6 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                                     const float band = 4.8e-7f * (fabsf(tFar) + n0) + 1e-30f;
                                     enter = !((tFar - n0) < -band);
                                 }
-#endif
                                 if (enter) m16 |= 1u << k;
                             }
                             if (r && m16) POOL_FILE_INSTANCES(m16, wy + b0);
@@ -428,7 +414,6 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 if (mine) POOL_TPOP();
 #undef POOL_RLF
 #undef POOL_RLU
-#if POOL_CHAIN_INST
                 // the rays that found instances enter their first one right away, together with the lanes already waiting for an
                 // instance step: one step that serves ~48 lanes instead of two that serve ~40 and ~23
                 isInst = (tcur != COOP_NONE) && (tcur != POOL_INBLAS) && (tcur & TAG_MASK) == TAG_INST;
@@ -436,11 +421,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 chainInst = nInst > 0 && PCAP - poolTop >= 64u + RESERVE;
                 if (!chainInst) continue;
                 goto pool_instance_step;
-#else
-                continue;
-#endif
             }
-#endif
             if (A.topFlat != 0u) {       // (INL: scenes with single-leaf instances, handled on the spot; node and instance records as scalar loads)
                 // Small top-level tree (<= 64 nodes): no walk.  Every node is looked at once, in index order (parents come
                 // before their children, DFS pre-order), by all lanes of the step together -- the node is the same for all
@@ -507,12 +488,10 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                     }
                     POOL_TPOP();
                 }
-#if POOL_CHAIN_INST
                 isInst = (tcur != COOP_NONE) && (tcur != POOL_INBLAS) && (tcur & TAG_MASK) == TAG_INST;
                 nInst = __popcll(__ballot(isInst));
                 chainInst = nInst > 0 && PCAP - poolTop >= 64u + RESERVE;
                 if (chainInst) goto pool_instance_step;
-#endif
                 continue;
             }
             if (isTop && tcur != COOP_NONE) {
@@ -546,9 +525,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             continue;
         }
         // ---- instance entry (radiance.cl:161-169): the BLAS root goes into the pool ----------------------------------
-#if POOL_CHAIN_INST
     pool_instance_step:
-#endif
         if (chainInst || (nInst > 0 && nInst * POOL_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE)) {
             const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
             if (__ballot(ready) == 0ull) { POOL_TEST(); continue; }
@@ -688,12 +665,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             const uint32_t tagBits = slotBits;
             while (__any((cntL | cntR) != 0u)) {
                 const uint32_t cl = min(cntL, POOL_PIECE), cr = min(cntR, POOL_PIECE);
-#if POOL_ENQ_BOTH
                 pool_enqueue2(A, L.queue, rays, L.best, lane, tagBits, cl, stL, cr, stR, qHead, qTail, tmin, tmax);
-#else
-                POOL_ENQ(tagBits, cl, stL);
-                POOL_ENQ(tagBits, cr, stR);
-#endif
                 stL += cl; cntL -= cl; stR += cr; cntR -= cr;
             }
             if (qTail - qHead >= POOL_TEST_MIN) POOL_TEST();
