@@ -616,6 +616,40 @@ def test_large_and_walked_top_level_trees(mods):
             rd.SetOption("top_flat", 1)
 
 
+def test_single_leaf_instances_inline_or_not(mods):
+    """instances whose BLAS is one small leaf (the quads of sample1) are tested inside the top-level step by default (`INL`
+    kernels) and go through the instance step and the test queue with `inline_leaf_roots` 0 (the other instantiation of the
+    pool kernels, whose top-level step reads its boxes by lane broadcast): same HitData as the reference-order kernel and
+    the same frame, bit for bit, either way"""
+    rd, scenes = mods
+    s = scenes.c1_cornell(160, 90, spp=2, depth=4, sphere_subdiv=3)
+    dev = scenes.DeviceScene(s)
+    rng = np.random.default_rng(11)
+    n = 20000
+    o = rng.uniform(-1.2, 1.2, (n, 3)).astype(np.float32) + np.array([0, 1, 0], np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    frames = []
+    try:
+        for inl in (1, 0):
+            rd.SetOption("inline_leaf_roots", inl)
+            for cull in (0, 1):
+                rd.SetOption("cull", cull)
+                for rec in (1, 2):
+                    ref = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, reference_order=True)
+                    got = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+                    assert np.array_equal(ref["hit"], got["hit"]), (inl, cull, rec)
+                    if rec == 1:
+                        assert np.array_equal(_bits(ref), _bits(got)), (inl, cull)
+                    assert ref["hit"].sum() > 1000
+                dev.set_rtprop(totalSamples=0)
+                dev.render()
+                frames.append(dev.read_scratch().copy())
+    finally:
+        rd.SetOption("inline_leaf_roots", 1); rd.SetOption("cull", -1)
+    for f in frames[1:]:
+        assert np.array_equal(frames[0].view(np.uint32), f.view(np.uint32))
+
+
 def test_foreign_blob_is_refused(mods):
     """a TLAS blob whose nodes are not in the reference's DFS pre-order (a foreign or corrupted cache file) is refused with a
     clear error at first use instead of being mis-sized on the GPU"""
