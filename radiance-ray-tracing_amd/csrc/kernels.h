@@ -92,6 +92,12 @@ struct PathStreams {
 // the L2, so every bin has SORT_REP replicas (a block uses replica blockIdx % SORT_REP) laid out bin-major: one linear
 // exclusive scan over bins x replicas then gives every (bin, replica) its output range.
 // bins: SORT_WORDS words, zeroed by the call; perm: 2 x nMax words.
+// SORT_ONE_KEY (default): ONE key -- origin cell major, direction octant minor -- and ONE permutation serve both the shadow
+// queries (same origin as the bounce ray; the octant only orders rays inside a cell) and the next bounce's rays: half the
+// atomics, counters and scan of the two-key version.
+#ifndef SORT_ONE_KEY
+#define SORT_ONE_KEY 1
+#endif
 constexpr uint32_t SORT_BINS = 1u << 15;             // 3 octant bits + 12 Morton bits
 constexpr uint32_t SORT_REP = 32u;
 constexpr uint32_t SORT_TILE = 4096u;                // counters per scan tile

@@ -652,7 +652,11 @@ __device__ __forceinline__ void sort_keys(const PathStreams& ps, const SortBox& 
 {
     const float4 so = ps.shO[j], ro = ps.nRayO[j], rd = ps.nRayD[j];
     kS = sort_cell(B, so.x, so.y, so.z);
+#if SORT_ONE_KEY
+    kE = (sort_cell(B, ro.x, ro.y, ro.z) << 3) | ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u));
+#else
     kE = (((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) << 12) | sort_cell(B, ro.x, ro.y, ro.z);
+#endif
 }
 // bins[key] += 1 for every active lane, returning the old value (the lane's slot) -- with the lanes of a wave that share a
 // key combined into ONE atomic (up to 8 distinct keys are peeled off this way, the rest go singly).  Coherent rays crowd
@@ -684,8 +688,12 @@ k_sort_hist(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32
         const bool active = j < m;
         uint32_t kS = 0, kE = 0;
         if (active) sort_keys(ps, B, j, kS, kE);
+#if SORT_ONE_KEY
+        sort_bin_add(bins, kE * SORT_REP + r, active);
+#else
         sort_bin_add(bins, kS * SORT_REP + r, active);
         sort_bin_add(bins + SORT_BINS * SORT_REP, kE * SORT_REP + r, active);
+#endif
     }
 }
 // exclusive scan inside tiles of SORT_TILE counters (256 threads x 16 consecutive counters), tile totals to sums[tile]
@@ -746,10 +754,16 @@ k_sort_scatter(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uin
         const bool active = j < m;
         uint32_t kS = 0, kE = 0;
         if (active) sort_keys(ps, B, j, kS, kE);
+#if SORT_ONE_KEY
+        const uint32_t cE = kE * SORT_REP + r;
+        const uint32_t pE = sort_bin_add(bins, cE, active);          // (the order inside a bin is arbitrary: no result depends on it)
+        if (active) permE[pE + sums[cE / SORT_TILE]] = j;
+#else
         const uint32_t cS = kS * SORT_REP + r, cE = SORT_BINS * SORT_REP + kE * SORT_REP + r;
         const uint32_t pS = sort_bin_add(bins, cS, active);          // (the order inside a bin is arbitrary: no result depends on it)
         const uint32_t pE = sort_bin_add(bins, cE, active);
         if (active) { permS[pS + sums[cS / SORT_TILE]] = j; permE[pE + sums[cE / SORT_TILE]] = j; }
+#endif
     }
 }
 
@@ -1396,11 +1410,12 @@ void launch_ray_sort(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr
 {
     if (!nMax) return;
     uint32_t* sums = bins + 2u * SORT_BINS * SORT_REP;
-    (void)hipMemsetAsync(bins, 0, (size_t)SORT_WORDS * sizeof(uint32_t), st);
+    const uint32_t arrays = SORT_ONE_KEY ? 1u : 2u;              // (one key: the first counter array and its tile sums only)
+    (void)hipMemsetAsync(bins, 0, (size_t)arrays * SORT_BINS * SORT_REP * sizeof(uint32_t), st);
     const uint32_t grid = std::min<uint32_t>(blocks_for(nMax, RDX_BLOCK), 256u * 8u);
     hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(RDX_BLOCK), 0, st, ps, mPtr, box, bins);
-    hipLaunchKernelGGL(k_sort_scan_tiles, dim3(SORT_TILES), dim3(256), 0, st, bins, sums);
-    hipLaunchKernelGGL(k_sort_scan_sums, dim3(2), dim3(1024), 0, st, sums);
+    hipLaunchKernelGGL(k_sort_scan_tiles, dim3(arrays * SORT_TILES / 2u), dim3(256), 0, st, bins, sums);
+    hipLaunchKernelGGL(k_sort_scan_sums, dim3(arrays), dim3(1024), 0, st, sums);
     hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(RDX_BLOCK), 0, st, ps, mPtr, box, bins, sums, permS, permE);
 }
 

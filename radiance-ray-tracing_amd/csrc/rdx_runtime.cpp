@@ -39,7 +39,8 @@ constexpr int RDX_MAX_DEVICES = 16;
 // one, whose rays are coherent as they come), the sort itself costs 5-7 ms per frame (device-scope atomics of the counting sort).
 // That was a net gain on the 10.4 M-triangle scene while its frame took 107 ms (-> 103.9); with the r02c engine it no longer is
 // (59.2 ms unsorted, 61.0 sorted: the sort costs 7.2 ms and saves 5.6; Sponza-class 25.0 vs 29.0) -- so the automatic rule is OFF
-// for every scene size until the sort is cheaper (LDS radix sort); `sort` = 1 still forces it.
+// for every scene size until the sort is cheaper (LDS radix sort); `sort` = 1 still forces it.  (One key and one
+// permutation for shadow and bounce rays, SORT_ONE_KEY, halved the sort to 3.9 ms: break-even at 10.4 M triangles, 57.2 vs 57.5 ms.)
 constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 0xffffffffu;
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
@@ -1498,7 +1499,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
                     g_timer.begin(&g.stats.ms_sort, G.s0);
                     launch_ray_sort(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permS, G.permE);
                     g_timer.end(G.s0);
-                    ps.permS = G.permS; ps.permE = G.permE;
+                    ps.permS = SORT_ONE_KEY ? G.permE : G.permS; ps.permE = G.permE;
                 }
                 const PathStreams psShadow = ps;
                 // the compacted survivors become the live paths of the next bounce
