@@ -104,6 +104,11 @@ constexpr uint32_t SORT_TILE = 4096u;                // counters per scan tile
 constexpr uint32_t SORT_TILES = 2u * SORT_BINS * SORT_REP / SORT_TILE;                  // both arrays
 constexpr uint32_t SORT_WORDS = 2u * SORT_BINS * SORT_REP + SORT_TILES;                 // counters + tile sums
 struct SortBox { float lo[3]; float inv[3]; };      // cell = (p - lo) * inv, clamped to 0..15
+// the same without device-scope atomics (kernels.hip k_sortg_*: per-block LDS histograms, one scan, LDS positions): ONE permutation of
+// nMax words; H: ray_sort_tiles_words() words of scratch
+void launch_ray_sort_tiles(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* H,
+                           uint32_t* perm);
+uint32_t ray_sort_tiles_words();
 void launch_ray_sort(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* bins,
                      uint32_t* permS, uint32_t* permE);
 

@@ -34,14 +34,11 @@ using namespace rdx;
 // handles
 // ------------------------------------------------------------------------------------------------
 constexpr int RDX_MAX_DEVICES = 16;
-// option "sort" -1: scenes with at least this many inner BVH nodes are sorted.  Measured (tools/gpu_sort_ab.sh, 1080p x 4 spp): the
-// sorted hand-out makes the traversal launches 7-10 % faster on the 262 k- and the 10.4 M-triangle scene (16 % slower on the 20 k
-// one, whose rays are coherent as they come), the sort itself costs 5-7 ms per frame (device-scope atomics of the counting sort).
-// That was a net gain on the 10.4 M-triangle scene while its frame took 107 ms (-> 103.9); with the r02c engine it no longer is
-// (59.2 ms unsorted, 61.0 sorted: the sort costs 7.2 ms and saves 5.6; Sponza-class 25.0 vs 29.0) -- so the automatic rule is OFF
-// for every scene size until the sort is cheaper (LDS radix sort); `sort` = 1 still forces it.  (One key and one
-// permutation for shadow and bounce rays, SORT_ONE_KEY, halved the sort to 3.9 ms: break-even at 10.4 M triangles, 57.2 vs 57.5 ms.)
-constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 0xffffffffu;
+// option "sort" -1: scenes with at least this many inner BVH nodes are sorted.  Measured with the r02d engine (1080p x 4 spp; unsorted
+// / sorted): 10.4 M triangles 56.9 / 54.3 ms (the sorted hand-out makes the traversal launches 9 % faster, the eight sorts cost
+// 1.5 ms), Sponza-class 24.5 / 24.6 (break-even), sample1 13.3 / 15.4 (its rays are coherent as they come; the sort scrambles the
+// pixel order).  The first version of the sort (device-scope atomics, option value 2) cost 7.2 ms per frame and lost everywhere.
+constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 1u << 20;
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
     DNode* tnodes = nullptr; DNode* ctnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
@@ -1284,7 +1281,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
     if (!strcmp(name, "user_shader_local_size")) { if (value < 1 || value > 1024) return fail("user_shader_local_size must be 1..1024"); g.userLocalSize = (int)value; return 0; }
-    if (!strcmp(name, "sort")) { g.sortRays = value < 0 ? -1 : (value != 0); return 0; }
+    if (!strcmp(name, "sort")) { g.sortRays = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }      // 1 = counting sort on per-block LDS histograms, 2 = its predecessor on device-scope atomics
     if (!strcmp(name, "textures")) { g.textures = value != 0; return 0; }
     if (!strcmp(name, "cull")) { g.cull = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
@@ -1495,11 +1492,12 @@ static int trace_rays_device(uint32_t width, uint32_t height)
                         HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.permE), (size_t)n0 * 4));
                         G.permCap = n0;
                     }
-                    if (!G.sortBins) HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.sortBins), (size_t)SORT_WORDS * 4));
+                    if (!G.sortBins) HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.sortBins), (size_t)std::max<uint32_t>(SORT_WORDS, ray_sort_tiles_words()) * 4));
                     g_timer.begin(&g.stats.ms_sort, G.s0);
-                    launch_ray_sort(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permS, G.permE);
+                    if (g.sortRays == 2) launch_ray_sort(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permS, G.permE);
+                    else launch_ray_sort_tiles(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permE);
                     g_timer.end(G.s0);
-                    ps.permS = SORT_ONE_KEY ? G.permE : G.permS; ps.permE = G.permE;
+                    ps.permS = (SORT_ONE_KEY || g.sortRays != 2) ? G.permE : G.permS; ps.permE = G.permE;
                 }
                 const PathStreams psShadow = ps;
                 // the compacted survivors become the live paths of the next bounce
