@@ -200,8 +200,10 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     bool lastOfAll = false;
     uint32_t resBase = 0, resEnd = 0;
     uint32_t rayIdx = COOP_NONE;
-    uint32_t tcur = COOP_NONE, tsp = 0;                    // top-level cursor / stack pointer
-    uint32_t markPrev = 0, finMark = 0;
+    uint32_t tcur = COOP_NONE, tsp = 0;                    // top-level cursor / stack pointer (flat top level: `tsp` counts the instances
+                                                           // still pending in the lane's bitmap instead)
+    uint32_t markPrev = 0;                                 // queue position the lane waits for: the tests of the instance it left before it
+                                                           // enters the next one -- and, once its walk is over, all of its tests (`finishing`)
     bool finishing = false, anyHit = (REC == 2);
     typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
@@ -210,7 +212,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     // LDS (A.topNeed = ceil(instances / 32) words per lane) plus their count in a register, instead of a stack of mask
     // entries -- a quarter to a tenth of the LDS (25 instances: 1 word instead of 9 per lane), which is residency.
     const bool flatTop = A.topFlat != 0u;
-    uint32_t instLeft = 0;
+#define instLeft tsp
     if (flatTop) for (uint32_t w = 0; w < A.topNeed; ++w) tstack[w * 64u] = 0u;
 #define POOL_INSTBITS (TAG_INST | IDX_MASK)            // top-level cursor in flat mode: "take the next instance from the bitmap"
 #define POOL_TPOP() do {                                                                               \
@@ -218,8 +220,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         else if (tsp == 0) tcur = COOP_NONE; else { --tsp; tcur = tstack[tsp * 64u]; }                 \
     } while (0)
 #define POOL_DROP() do {       /* the ray needs nothing more from the top level (shadow ray answered) */ \
-        tcur = COOP_NONE; tsp = 0;                                                                     \
-        if (flatTop && instLeft) { for (uint32_t w_ = 0; w_ < A.topNeed; ++w_) tstack[w_ * 64u] = 0u; instLeft = 0; } \
+        tcur = COOP_NONE;                                                                              \
+        if (flatTop && instLeft) { for (uint32_t w_ = 0; w_ < A.topNeed; ++w_) tstack[w_ * 64u] = 0u; }  \
+        tsp = 0;                                                                                       \
     } while (0)
 #define POOL_FILE_INSTANCES(M16, FIRST) do {            /* up to 16 instances FIRST.. (wave-uniform) with lane mask M16 */ \
         if (flatTop) {                                                                                 \
@@ -250,8 +253,8 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
 #endif
         // a lane whose instance has left the pool moves on along its top-level stack
         if (tcur == POOL_INBLAS && pendN[lane] == 0u) { POOL_TPOP(); markPrev = qTail; }       // the tests of the instance just left
-        if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; finMark = qTail; }
-        const bool done = finishing && (int32_t)(qHead - finMark) >= 0;
+        if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; markPrev = qTail; }
+        const bool done = finishing && (int32_t)(qHead - markPrev) >= 0;
         const bool isFree = (rayIdx == COOP_NONE);
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
         const bool has = (tcur != COOP_NONE) && (tcur != POOL_INBLAS);
@@ -684,6 +687,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     pol.retire(st);
 #undef POOL_TEST
 #undef POOL_ENQ
+#undef instLeft
 #undef POOL_TPOP
 #undef POOL_DROP
 #undef POOL_FILE_INSTANCES
