@@ -7,7 +7,9 @@ workload, scene and accumulators already resident in HBM.  Default workload = th
 configs[2], the configuration the north star's 1-GPU target is stated on); the sample1 scene (configs[1]) and the
 10.4 M-triangle scene (configs[4] geometry) are always timed as well and reported under `also` (N = 1).
 N > 1: one process per GPU (torch.distributed / RCCL), the frame is sharded by interleaved 64x64 image tiles, no
-collective while rendering, one RGBA8 gather to rank 0 at frame end -- inside the timed region.
+collective while rendering, one RGBA8 gather to rank 0 at frame end -- inside the timed region.  Weak scaling (default): the
+frame has N x 4 samples per pixel, so every GPU keeps the rays of the N = 1 frame (BASELINE configs 3 / 4 are such frames);
+the N = 1 frame split N ways is timed as well (`also.strong_scaling_of_the_n1_frame`; --scaling strong makes it the headline).
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline      dominant kernel (k_fused_pool = shadow rays of bounce d + closest-hit rays of bounce d+1 per launch).
@@ -54,8 +56,8 @@ WORKLOADS = {
 }
 
 
-def workload_label(key, a):
-    return "%s, %dx%d, %d spp, depth %d" % (WORKLOADS[key][1], a.width, a.height, a.spp, a.depth)
+def workload_label(key, a, spp=None):
+    return "%s, %dx%d, %d spp, depth %d" % (WORKLOADS[key][1], a.width, a.height, a.spp if spp is None else spp, a.depth)
 
 
 def algorithmic_bytes(top, inst, bot, tri, rays):
@@ -287,6 +289,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = every GPU keeps the rays of the N = 1 frame (the frame has N x --spp samples per pixel, tiles sharded "
+                         "over the ranks: BASELINE configs 3 / 4 are such frames); strong = the N = 1 frame itself is split N ways")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic / achieved become null)")
     ap.add_argument("--no-reference", action="store_true", help="skip the informational run of the reference's own kernel")
@@ -337,9 +342,13 @@ def main():
     plt = rd.Platform.GetPlatform(local_rank)
     apply_options(rd, args)
 
-    def run_workload(key, steps, warmup, want_roofline):
+    # weak scaling: per-GPU work is that of the N = 1 frame -- the frame is rendered with N x spp samples per pixel and its 64x64
+    # tiles are dealt to the ranks (what BASELINE configs 3 and 4 do: 64 / 256 spp over 8 GPUs); strong: the N = 1 frame split N ways
+    spp_main = args.spp * world if (world > 1 and args.scaling == "weak") else args.spp
+
+    def run_workload(key, steps, warmup, want_roofline, spp=None):
         cfg, _ = WORKLOADS[key]
-        scene = scenes.CONFIGS[cfg](args.width, args.height, args.spp, args.depth)
+        scene = scenes.CONFIGS[cfg](args.width, args.height, spp_main if spp is None else spp, args.depth)
         dev = scenes.DeviceScene(scene, plt)
         sharder = rdist.FrameSharder(rd, plt, args.width, args.height, rank, world, 64, 64, torch.device("cuda", local_rank))
 
@@ -420,6 +429,19 @@ def main():
     del dev                                                      # frees nothing on the device (the API has no release), drops the host side
 
     also = {}
+    if world > 1 and args.scaling == "weak":
+        # the same ranks on the N = 1 frame (strong scaling), for the record: a depth-8 frame is 17 dependent launches, so 1/N of a
+        # 1080p x 4 spp frame sits on the per-launch floor
+        import torch.distributed as tdist
+        st_s = max(3, args.steps // 2)
+        _, dev_s, a_s, dt_s, _ = run_workload(args.workload, st_s, 1, False, spp=args.spp)
+        del dev_s
+        t_s = torch.tensor([float(a_s["primary"] + a_s["bounce"] + a_s["shadow"])], dtype=torch.float64, device="cuda")
+        tdist.all_reduce(t_s)
+        tm_s = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
+        tdist.all_reduce(tm_s, op=tdist.ReduceOp.MAX)
+        also["strong_scaling_of_the_n1_frame"] = {"workload": workload_label(args.workload, args), "Mrays_per_s": round(float(t_s[0]) / float(tm_s[0]) / 1e6, 2),
+                                                  "ms_per_frame": round(1e3 * float(tm_s[0]) / st_s, 3), "steps": st_s}
     also_keys = [k for k in (args.also.split(",") if args.also is not None else
                              ([w for w in ("sample1", "sponza", "sanmiguel") if w != args.workload] if world == 1 else [])) if k]
     for key in also_keys:
@@ -458,11 +480,12 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": workload_label(args.workload, args), "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth,
+        "config": {"workload": workload_label(args.workload, args, spp_main), "width": args.width, "height": args.height, "spp": spp_main, "depth": args.depth,
+                   "spp_per_gpu_equivalent": args.spp,
                    "sharding": "none" if world == 1 else "64x64 image tiles interleaved over %d ranks + RGBA8 gather" % world,
                    "traversal": "bit-identical to the reference's exhaustive walk (verified against the reference's own device code, tests/test_gpu_reference.py)",
                    # sample groups traced concurrently on their own streams (library rule: 2 for chunks of <= 4.7 M paths);
