@@ -6,7 +6,13 @@
 //
 // build: g++ -std=c++17 -Iinclude samples/cornell_rd.cpp -Lradiance-ray-tracing_amd -lrdx
 //            -Wl,-rpath,$PWD/radiance-ray-tracing_amd -o cornell_rd
-// run:   ./cornell_rd 320 180 8 out.ppm
+// run:   ./cornell_rd 320 180 8 out.ppm [frames per view = 2] [views = 1]
+//
+// With views > 1 it plays the host loop of the reference's interactive sample (samples/sample1.cpp:447-548) without a window:
+// every view is an "edit" -- the camera is moved, the camera buffer rewritten and totalSamples reset to 0, which is what the
+// reference's inspector does when a property changes -- followed by `frames` progressive frames (TraceRays; totalSamples +=
+// batchSize); the last frame of each view is written to <out minus .ppm>_<view>.ppm and the frame time is printed.
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -47,6 +53,7 @@ int main(int argc, char** argv)
     const int W = argc > 1 ? atoi(argv[1]) : 320, H = argc > 2 ? atoi(argv[2]) : 180;
     const unsigned spp = argc > 3 ? (unsigned)atoi(argv[3]) : 8;
     const std::string out = argc > 4 ? argv[4] : "cornell_rd.ppm";
+    const int framesPerView = argc > 5 ? atoi(argv[5]) : 2, views = argc > 6 ? atoi(argv[6]) : 1;
 
     // ---- scene ------------------------------------------------------------------------------------
     HostScene S;
@@ -145,20 +152,38 @@ int main(int argc, char** argv)
     RD::BindPipeline(plt, pipeline);
     RD::BindDescriptorSet(plt, descSet);
 
-    // ---- two progressive frames (sample1.cpp:447-498) ----------------------------------------------------
-    for (int frame = 0; frame < 2; ++frame) {
-        RD::TraceRays(plt, 0, 0, 0, W, H);
-        RD::ReadBuffer(plt, rdImage, imageSize, image.data());
-        RD::RayTraceProperties p;
-        RD::ReadBuffer(plt, rdRTProp, sizeof p, &p);
-        p.totalSamples += p.batchSize;
-        RD::WriteBuffer(plt, rdRTProp, sizeof p, &p);
+    // ---- the host loop (sample1.cpp:447-548): per view an edit + reset, then progressive frames -------------------------
+    auto writePPM = [&](const std::string& path) {
+        FILE* fp = fopen(path.c_str(), "wb");
+        if (!fp) return false;
+        fprintf(fp, "P6\n%d %d\n255\n", W, H);
+        for (int i = 0; i < W * H; ++i) fwrite(&image[4 * i], 1, 3, fp);
+        fclose(fp);
+        printf("Writing image with extent: <%d, %d> to %s\n", W, H, path.c_str());
+        return true;
+    };
+    for (int view = 0; view < views; ++view) {
+        if (view > 0) {          // an edit: orbit the camera a little, rewrite its buffer, restart the accumulation
+            camData.x = 2.5f * (float)view; camData.wy = -3.14159f + 0.15f * (float)view;
+            RD::WriteBuffer(plt, rdCamData, sizeof(camData), &camData);
+            RD::RayTraceProperties p;
+            RD::ReadBuffer(plt, rdRTProp, sizeof p, &p);
+            p.totalSamples = 0;
+            RD::WriteBuffer(plt, rdRTProp, sizeof p, &p);
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int frame = 0; frame < framesPerView; ++frame) {
+            RD::TraceRays(plt, 0, 0, 0, W, H);
+            RD::ReadBuffer(plt, rdImage, imageSize, image.data());
+            RD::RayTraceProperties p;
+            RD::ReadBuffer(plt, rdRTProp, sizeof p, &p);
+            p.totalSamples += p.batchSize;
+            RD::WriteBuffer(plt, rdRTProp, sizeof p, &p);
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (views > 1) printf("view %d: %d frames of %u spp, %.2f ms per frame incl. read-back\n", view, framesPerView, spp, ms / framesPerView);
+        const std::string path = views > 1 ? out.substr(0, out.rfind(".ppm")) + "_" + std::to_string(view) + ".ppm" : out;
+        if (!writePPM(path)) return 1;
     }
-    FILE* fp = fopen(out.c_str(), "wb");
-    if (!fp) return 1;
-    fprintf(fp, "P6\n%d %d\n255\n", W, H);
-    for (int i = 0; i < W * H; ++i) fwrite(&image[4 * i], 1, 3, fp);
-    fclose(fp);
-    printf("Writing image with extent: <%d, %d> to %s\n", W, H, out.c_str());
     return 0;
 }
