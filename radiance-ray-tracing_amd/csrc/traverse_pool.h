@@ -74,14 +74,15 @@ __host__ __device__ inline uint32_t pool_words_per_wave(uint32_t topNeed, uint32
 static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rule (derive_accel) must match the pool item layout");
 #define POOL_INBLAS 0xfffffffeu        // top-level cursor of a lane whose instance is in the pool
 #ifndef POOL_TEST_MIN
-#define POOL_TEST_MIN 32u              // queued triangle tests a test step waits for (at 6 waves / SIMD: 32 -> 48 -> 64: +1 %, +2 % frame time)
+#define POOL_TEST_MIN 16u              // queued triangle tests a test step waits for (final engine, with POOL_REPEAT 16: 16 / 24 / 32 -> 24.09 / 24.11 / 24.31 ms, Sponza-class)
 #endif
 // POOL_REPEAT: pool steps run back to back (while the pool holds a full batch) before the lane states are looked at again --
 // the step selection at the top of the loop is a good part of a step's scalar instructions.  1080p frame, sample1 /
 // Sponza-class / 10.4 M triangles: 1 -> 13.62 / 27.64 / 72.06 ms, 2 -> 13.52 / 27.34 / 70.92, 3 -> 13.51 / 27.23 / 70.21,
-// 4 -> 13.48 / 27.15 / 70.36.
+// 4 -> 13.48 / 27.15 / 70.36.  Re-swept on the final engine (r02e; test threshold 24): 3 -> 13.36 / 24.58 / 54.18, 6 -> 13.32 / 24.23 /
+// 53.43, 12 -> 13.30 / 24.10 / 53.26, 32 -> 13.24 / 24.11 / 53.63; 16 with a test threshold of 16: 13.24 / 24.09 / 53.21.
 #ifndef POOL_REPEAT
-#define POOL_REPEAT 3u
+#define POOL_REPEAT 16u
 #endif
 #ifndef POOL_W_TOP
 #define POOL_W_TOP 8                   // weights (in quarters) of a lane waiting for a top-level / instance step against a pooled node
