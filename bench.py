@@ -7,9 +7,10 @@ workload, scene and accumulators already resident in HBM.  Default workload = th
 configs[2], the configuration the north star's 1-GPU target is stated on); the sample1 scene (configs[1]) and the
 10.4 M-triangle scene (configs[4] geometry) are always timed as well and reported under `also` (N = 1).
 N > 1: one process per GPU (torch.distributed / RCCL), the frame is sharded by interleaved 64x64 image tiles, no
-collective while rendering, one RGBA8 gather to rank 0 at frame end -- inside the timed region.  Weak scaling (default): the
-frame has N x 4 samples per pixel, so every GPU keeps the rays of the N = 1 frame (BASELINE configs 3 / 4 are such frames);
-the N = 1 frame split N ways is timed as well (`also.strong_scaling_of_the_n1_frame`; --scaling strong makes it the headline).
+collective while rendering, one RGBA8 gather to rank 0 at frame end -- inside the timed region.  The headline at every N is
+the metric's own frame (1920x1080, 4 spp, depth 8) split N ways: STRONG scaling, what the north star's ">= 6x at 8 GPUs" is
+about.  The weak-scaling figure (N x 4 samples per pixel, every GPU keeps the rays of the N = 1 frame: BASELINE configs 3 / 4
+are such frames) is timed as well and reported under `also.weak_scaling_n_x_spp`; --scaling weak makes it the headline.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline      dominant kernel (k_fused_pool = shadow rays of bounce d + closest-hit rays of bounce d+1 per launch).
@@ -110,13 +111,33 @@ def _rocprof():
     return None
 
 
+PROFILER_ENV_MARKS = ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_", "ROCPROF_", "ROCP_", "HSA_TOOLS_LIB")
+
+
+def under_profiler():
+    """True when this process already runs under rocprofv3 (its tool library is preloaded and has initialised the GPU): a nested
+    profiler pass -- a `#!/usr/bin/env python3` launcher that would exec its target from a GPU-initialised process -- must not
+    be started from here (tools/gpu_profile.sh and friends profile `bench.py --no-pmc --no-reference` themselves)."""
+    if any(k.startswith(PROFILER_ENV_MARKS) for k in os.environ):
+        return True
+    return "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if not k.startswith(PROFILER_ENV_MARKS)}
+    if "rocprof" in env.get("LD_PRELOAD", ""):
+        env.pop("LD_PRELOAD")
+    env["TMPDIR"] = "/tmp"
+    return env
+
+
 def pmc_pass(counters, child_args, timeout_s=300):
     """-> {kernel name: {"launches": n, counter: average per launch}} or None"""
     prof = _rocprof()
-    if prof is None:
+    if prof is None or under_profiler():
         return None
     tmp = tempfile.mkdtemp(prefix="rdx_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = _clean_env()
     cmd = [prof, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "p", "--",
                                         "python3", os.path.join(ROOT, "bench.py"), "--pmc-child"] + child_args
     try:
@@ -255,7 +276,16 @@ def cpu_baseline(scene, budget_s=20.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))           # a 1-GPU box's CPU share is 16 cores
+    nproc = os.cpu_count() or cores
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cores = max(1, min(cores, 16))           # a 1-GPU box's CPU share is 16 cores, whatever nproc says (256 on the pool's hosts)
     rng = np.random.default_rng(0)
     probe = rng.choice(n, 4096, replace=False).astype(np.uint32)
     osc.render(nthreads=cores, pixels=probe[:256])
@@ -271,6 +301,7 @@ def cpu_baseline(scene, budget_s=20.0):
         rays += d["rays"][0] + d["rays"][1]
         reps += 1
     return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "nproc": nproc, "cpu_model": model, "threads": cores,
             "sample": "%d random pixels of the same frame (%d spp, depth %d) x %d passes, %.1f s, %d reference-algorithm rays "
                       "(incl. the reference's duplicate re-trace after a primary miss)"
                       % (m, int(scene.rtprop["batchSize"]), int(scene.rtprop["depth"]), reps, dt, rays)}
@@ -282,16 +313,16 @@ STAGE_KEYS = ("ms_extend", "ms_shadow", "ms_shade", "ms_generate", "ms_accumulat
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="sponza", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = every GPU keeps the rays of the N = 1 frame (the frame has N x --spp samples per pixel, tiles sharded "
-                         "over the ranks: BASELINE configs 3 / 4 are such frames); strong = the N = 1 frame itself is split N ways")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="N > 1: strong (default) = the metric's own frame (1920x1080, --spp samples per pixel) is split N ways; weak = every "
+                         "GPU keeps the rays of the N = 1 frame (the frame has N x --spp samples per pixel: BASELINE configs 3 / 4 are such frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic / achieved become null)")
     ap.add_argument("--no-reference", action="store_true", help="skip the informational run of the reference's own kernel")
@@ -306,9 +337,7 @@ def main():
     ap.add_argument("--also", default=None, help="comma list of extra workloads to time (reported under 'also'); default at N=1: the other two")
     args = ap.parse_args()
 
-    if args.pmc_child:
-        import __graft_entry__ as ge
-        ge.build()
+    if args.pmc_child:          # (the parent has built everything; no compiler runs inside the profiled process)
         pmc_child(args)
         return
 
@@ -424,24 +453,27 @@ def main():
         rays_total, rays_pb = float(rays_local), float(acc["primary"] + acc["bounce"])
 
     tlas_blob = None
-    if rank == 0 and world == 1 and not args.no_reference:
+    if rank == 0 and world == 1 and not args.no_reference and not under_profiler():
         tlas_blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
     del dev                                                      # frees nothing on the device (the API has no release), drops the host side
 
     also = {}
-    if world > 1 and args.scaling == "weak":
-        # the same ranks on the N = 1 frame (strong scaling), for the record: a depth-8 frame is 17 dependent launches, so 1/N of a
-        # 1080p x 4 spp frame sits on the per-launch floor
+    if world > 1:
+        # the other scaling mode on the same ranks, for the record.  strong headline -> also the weak figure (N x spp samples per
+        # pixel, every GPU keeps the rays of the N = 1 frame); weak headline -> also the metric's own frame split N ways
         import torch.distributed as tdist
-        st_s = max(3, args.steps // 2)
-        _, dev_s, a_s, dt_s, _ = run_workload(args.workload, st_s, 1, False, spp=args.spp)
+        other_weak = args.scaling == "strong"
+        spp_o = args.spp * world if other_weak else args.spp
+        st_s = max(3, min(args.steps // 2, 20))
+        _, dev_s, a_s, dt_s, _ = run_workload(args.workload, st_s, 1, False, spp=spp_o)
         del dev_s
         t_s = torch.tensor([float(a_s["primary"] + a_s["bounce"] + a_s["shadow"])], dtype=torch.float64, device="cuda")
         tdist.all_reduce(t_s)
         tm_s = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
         tdist.all_reduce(tm_s, op=tdist.ReduceOp.MAX)
-        also["strong_scaling_of_the_n1_frame"] = {"workload": workload_label(args.workload, args), "Mrays_per_s": round(float(t_s[0]) / float(tm_s[0]) / 1e6, 2),
-                                                  "ms_per_frame": round(1e3 * float(tm_s[0]) / st_s, 3), "steps": st_s}
+        also["weak_scaling_n_x_spp" if other_weak else "strong_scaling_of_the_n1_frame"] = {
+            "workload": workload_label(args.workload, args, spp_o), "Mrays_per_s": round(float(t_s[0]) / float(tm_s[0]) / 1e6, 2),
+            "ms_per_frame": round(1e3 * float(tm_s[0]) / st_s, 3), "steps": st_s}
     also_keys = [k for k in (args.also.split(",") if args.also is not None else
                              ([w for w in ("sample1", "sponza", "sanmiguel") if w != args.workload] if world == 1 else [])) if k]
     for key in also_keys:
@@ -468,7 +500,7 @@ def main():
     pixels = args.width * args.height if world == 1 else None
     frame_bytes = bytes_extend_frame + bytes_shadow_frame + 184 * acc["hits"] / steps + (20 * pixels if pixels else 0)
     meas = {"traffic": None, "achieved": None, "issue": None}
-    if world == 1 and not args.no_pmc:
+    if world == 1 and not args.no_pmc and not under_profiler():
         meas = measured_roofline(kernel_name, trav_s, launches, option_args(args))
     achieved = meas["achieved"]
     out = {
@@ -487,7 +519,9 @@ def main():
         "config": {"workload": workload_label(args.workload, args, spp_main), "width": args.width, "height": args.height, "spp": spp_main, "depth": args.depth,
                    "spp_per_gpu_equivalent": args.spp,
                    "sharding": "none" if world == 1 else "64x64 image tiles interleaved over %d ranks + RGBA8 gather" % world,
-                   "traversal": "bit-identical to the reference's exhaustive walk (verified against the reference's own device code, tests/test_gpu_reference.py)",
+                   "traversal": "culled walk (option cull, automatic for this scene): skips only subtrees / leaves that provably cannot change the result "
+                                "(error bound in DESIGN.md 4.1c); verified bit-identical to the reference's own device code on the test corpus "
+                                "(tests/test_gpu_reference.py, tests/test_gpu_cull.py); cull=0 is the exhaustive walk",
                    # sample groups traced concurrently on their own streams (library rule: 2 for chunks of <= 4.7 M paths);
                    # with more than one, the per-launch durations behind `roofline` overlap in time
                    "sample_groups": acc.get("groups", 1)},

@@ -86,31 +86,16 @@ struct PathStreams {
     const uint32_t* permE;
 };
 
-// per-bounce ray sort: counting sort of the m survivors of shade(d) by (direction octant, Morton code of the origin's cell in
-// a 16^3 grid over the scene box) into two permutations, one for the shadow queries (key: origin cell only, the direction is
-// the light's) and one for the next bounce's rays.  Coherent rays crowd into few bins and same-address atomics serialise in
-// the L2, so every bin has SORT_REP replicas (a block uses replica blockIdx % SORT_REP) laid out bin-major: one linear
-// exclusive scan over bins x replicas then gives every (bin, replica) its output range.
-// bins: SORT_WORDS words, zeroed by the call; perm: 2 x nMax words.
-// SORT_ONE_KEY (default): ONE key -- origin cell major, direction octant minor -- and ONE permutation serve both the shadow
-// queries (same origin as the bounce ray; the octant only orders rays inside a cell) and the next bounce's rays: half the
-// atomics, counters and scan of the two-key version.
-#ifndef SORT_ONE_KEY
-#define SORT_ONE_KEY 1
-#endif
-constexpr uint32_t SORT_BINS = 1u << 15;             // 3 octant bits + 12 Morton bits
-constexpr uint32_t SORT_REP = 32u;
+// per-bounce ray sort (option "sort"): counting sort of the m survivors of shade(d) by (origin cell -- the high bits of the Morton
+// code of the origin in a 16^3 grid over the scene box -- then direction octant) into ONE permutation that serves the shadow
+// queries and the next bounce's rays alike (same origin).  No device-scope atomics: per-block LDS histograms, one scan, LDS
+// positions (kernels.hip k_sortg_*).
 constexpr uint32_t SORT_TILE = 4096u;                // counters per scan tile
-constexpr uint32_t SORT_TILES = 2u * SORT_BINS * SORT_REP / SORT_TILE;                  // both arrays
-constexpr uint32_t SORT_WORDS = 2u * SORT_BINS * SORT_REP + SORT_TILES;                 // counters + tile sums
 struct SortBox { float lo[3]; float inv[3]; };      // cell = (p - lo) * inv, clamped to 0..15
-// the same without device-scope atomics (kernels.hip k_sortg_*: per-block LDS histograms, one scan, LDS positions): ONE permutation of
-// nMax words; H: ray_sort_tiles_words() words of scratch
+// perm: nMax words; H: ray_sort_tiles_words() words of scratch
 void launch_ray_sort_tiles(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* H,
                            uint32_t* perm);
 uint32_t ray_sort_tiles_words();
-void launch_ray_sort(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* bins,
-                     uint32_t* permS, uint32_t* permE);
 
 // LDS words one wave of the cooperative / pool engine needs for the given stack needs (traverse_coop.h, traverse_pool.h)
 uint32_t coop_lds_words(uint32_t coopNeed);

@@ -539,9 +539,6 @@ __device__ __forceinline__ void fill_hit_info(const AccelView& A, uint32_t instS
 #ifndef RDX_SHADE_BLOCK
 #define RDX_SHADE_BLOCK 256
 #endif
-#ifndef RDX_SHADE_OCTANT_BINS
-#define RDX_SHADE_OCTANT_BINS 0       // experiment: measured no gain (sample1 -0.4 %, Sponza-class +1.4 % traversal time)
-#endif
 __global__ void __launch_bounds__(RDX_SHADE_BLOCK, RDX_SHADE_WAVES)
 k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ nOut,
         uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
@@ -584,32 +581,6 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
     // LDS first and one lane per block moves the cursor.
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
-#if RDX_SHADE_OCTANT_BINS
-    // Within the block the survivors are written grouped by the sign octant of their next direction (a counting sort
-    // on 3 bits through LDS): the next bounce's waves then hold rays that start in the same image neighbourhood AND
-    // head the same way, which the traversal rewards (tools/sort_probe.py).  Order never changes a result.
-    constexpr uint32_t NW = RDX_SHADE_BLOCK / 64;
-    __shared__ uint32_t s_cnt[8][NW], s_off[8][NW];
-    const uint32_t key = !alive ? 8u : ((p.nextRayDirection.x < 0.0f ? 1u : 0u) | (p.nextRayDirection.y < 0.0f ? 2u : 0u) |
-                                        (p.nextRayDirection.z < 0.0f ? 4u : 0u));
-    uint32_t rank = 0;
-#pragma unroll
-    for (uint32_t o = 0; o < 8; ++o) {
-        const unsigned long long mo = __ballot(key == o);
-        if (lane == 0) s_cnt[o][wave] = (uint32_t)__popcll(mo);
-        if (key == o) rank = (uint32_t)__popcll(mo & ltMask);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t o = 0; o < 8; ++o) for (uint32_t w = 0; w < NW; ++w) tot += s_cnt[o][w];
-        uint32_t run = tot ? atomicAdd(nOut, tot) : 0u;
-        for (uint32_t o = 0; o < 8; ++o) for (uint32_t w = 0; w < NW; ++w) { s_off[o][w] = run; run += s_cnt[o][w]; }
-    }
-    __syncthreads();
-    if (!alive) return;
-    const uint32_t j = s_off[key][wave] + rank;
-#else
     __shared__ uint32_t s_cnt[RDX_SHADE_BLOCK / 64], s_base;
     const unsigned long long m = __ballot(alive);
     if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
@@ -624,7 +595,6 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
     uint32_t base = s_base;
     for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
     const uint32_t j = base + (uint32_t)__popcll(m & ltMask);
-#endif
     const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
     const f3 lit = Cc + T * p.color;               // color += contribution * payload.color (shader.cl:240)
     const f3 occ = Cc + T * p.colorOccluded;
@@ -647,54 +617,6 @@ __device__ __forceinline__ uint32_t sort_cell(const SortBox& B, float x, float y
     const uint32_t cy = (uint32_t)fminf(fmaxf((y - B.lo[1]) * B.inv[1], 0.0f), 15.0f);
     const uint32_t cz = (uint32_t)fminf(fmaxf((z - B.lo[2]) * B.inv[2], 0.0f), 15.0f);
     return spread4(cx) | (spread4(cy) << 1) | (spread4(cz) << 2);            // 12-bit Morton code
-}
-__device__ __forceinline__ void sort_keys(const PathStreams& ps, const SortBox& B, uint32_t j, uint32_t& kS, uint32_t& kE)
-{
-    const float4 so = ps.shO[j], ro = ps.nRayO[j], rd = ps.nRayD[j];
-    kS = sort_cell(B, so.x, so.y, so.z);
-#if SORT_ONE_KEY
-    kE = (sort_cell(B, ro.x, ro.y, ro.z) << 3) | ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u));
-#else
-    kE = (((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u)) << 12) | sort_cell(B, ro.x, ro.y, ro.z);
-#endif
-}
-// bins[key] += 1 for every active lane, returning the old value (the lane's slot) -- with the lanes of a wave that share a
-// key combined into ONE atomic (up to 8 distinct keys are peeled off this way, the rest go singly).  Coherent rays crowd
-// into few bins: without the aggregation a bounce's 2 M atomics on a few dozen hot words took 2-4 ms.
-__device__ __forceinline__ uint32_t sort_bin_add(uint32_t* __restrict__ bins, uint32_t key, bool active)
-{
-    const uint32_t lane = __lane_id();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    unsigned long long todo = __ballot(active);
-    uint32_t leader = lane, rank = 0, cnt = 1;             // a lane not peeled off below is a group of its own
-    for (int it = 0; it < 8 && todo != 0ull; ++it) {
-        const int l0 = __ffsll((long long)todo) - 1;
-        const uint32_t k0 = __shfl(key, l0);
-        const unsigned long long same = __ballot(active && key == k0) & todo;
-        if ((same >> lane) & 1ull) { leader = (uint32_t)l0; rank = (uint32_t)__popcll(same & lt); cnt = (uint32_t)__popcll(same); }
-        todo &= ~same;
-    }
-    uint32_t base = 0;
-    if (active && leader == lane) base = atomicAdd(&bins[key], cnt);       // every group's atomic is in flight at once
-    return __shfl(base, leader) + rank;
-}
-__global__ void __launch_bounds__(RDX_BLOCK)
-k_sort_hist(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32_t* __restrict__ bins)
-{
-    // grid-stride over the m survivors (m lives on the device; the grid is sized for a resident set, not for the bound)
-    const uint32_t m = *mPtr, r = blockIdx.x % SORT_REP;
-    for (uint32_t base = blockIdx.x * RDX_BLOCK; base < m; base += gridDim.x * RDX_BLOCK) {
-        const uint32_t j = base + threadIdx.x;
-        const bool active = j < m;
-        uint32_t kS = 0, kE = 0;
-        if (active) sort_keys(ps, B, j, kS, kE);
-#if SORT_ONE_KEY
-        sort_bin_add(bins, kE * SORT_REP + r, active);
-#else
-        sort_bin_add(bins, kS * SORT_REP + r, active);
-        sort_bin_add(bins + SORT_BINS * SORT_REP, kE * SORT_REP + r, active);
-#endif
-    }
 }
 // exclusive scan inside tiles of SORT_TILE counters (256 threads x 16 consecutive counters), tile totals to sums[tile]
 __global__ void __launch_bounds__(256)
@@ -725,49 +647,7 @@ k_sort_scan_tiles(uint32_t* __restrict__ bins, uint32_t* __restrict__ sums)
     }
     if (t == 255u) sums[blockIdx.x] = part[255];
 }
-// exclusive scan of the tile totals of each of the two arrays (one block per array, SORT_TILES / 2 <= 1024 tiles)
-__global__ void __launch_bounds__(1024)
-k_sort_scan_sums(uint32_t* __restrict__ sums)
-{
-    static_assert(SORT_TILES / 2u <= 1024u, "one thread per tile");
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x, n = SORT_TILES / 2u;
-    uint32_t* s = sums + blockIdx.x * n;
-    const uint32_t v = t < n ? s[t] : 0u;
-    part[t] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t x = t >= off ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
-    }
-    if (t < n) s[t] = part[t] - v;
-}
-__global__ void __launch_bounds__(RDX_BLOCK)
-k_sort_scatter(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32_t* __restrict__ bins, const uint32_t* __restrict__ sums,
-               uint32_t* __restrict__ permS, uint32_t* __restrict__ permE)
-{
-    const uint32_t m = *mPtr, r = blockIdx.x % SORT_REP;
-    for (uint32_t base = blockIdx.x * RDX_BLOCK; base < m; base += gridDim.x * RDX_BLOCK) {
-        const uint32_t j = base + threadIdx.x;
-        const bool active = j < m;
-        uint32_t kS = 0, kE = 0;
-        if (active) sort_keys(ps, B, j, kS, kE);
-#if SORT_ONE_KEY
-        const uint32_t cE = kE * SORT_REP + r;
-        const uint32_t pE = sort_bin_add(bins, cE, active);          // (the order inside a bin is arbitrary: no result depends on it)
-        if (active) permE[pE + sums[cE / SORT_TILE]] = j;
-#else
-        const uint32_t cS = kS * SORT_REP + r, cE = SORT_BINS * SORT_REP + kE * SORT_REP + r;
-        const uint32_t pS = sort_bin_add(bins, cS, active);          // (the order inside a bin is arbitrary: no result depends on it)
-        const uint32_t pE = sort_bin_add(bins, cE, active);
-        if (active) { permS[pS + sums[cS / SORT_TILE]] = j; permE[pE + sums[cE / SORT_TILE]] = j; }
-#endif
-    }
-}
-
-// Global ray sort without device-scope atomics (option "sort" 1).  Counting sort over SORT_GBINS = 4096 keys (the 9 high bits of
+// Per-bounce ray sort (option "sort" 1), without device-scope atomics.  Counting sort over SORT_GBINS = 4096 keys (the 9 high bits of
 // the origin's Morton cell, direction octant; 10 / 11 / 12 key bits: 55.2 / 54.6 / 54.3 ms on the 10.4 M-triangle scene) in the
 // classic three steps of a radix pass: (A) every block histograms ITS
 // tiles of 4096 consecutive paths in LDS and writes its column of the (key, block) count matrix, (B) one exclusive scan of the
@@ -1486,20 +1366,6 @@ void launch_ray_sort_tiles(hipStream_t st, const PathStreams& ps, const uint32_t
     hipLaunchKernelGGL(k_sortg_scatter, dim3(cols), dim3(256), 0, st, ps, mPtr, box, H, sums, perm);
 }
 uint32_t ray_sort_tiles_words() { return SORT_GBINS * SORT_GCOLS + SORT_GSCAN_TILES; }
-
-void launch_ray_sort(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* bins,
-                     uint32_t* permS, uint32_t* permE)
-{
-    if (!nMax) return;
-    uint32_t* sums = bins + 2u * SORT_BINS * SORT_REP;
-    const uint32_t arrays = SORT_ONE_KEY ? 1u : 2u;              // (one key: the first counter array and its tile sums only)
-    (void)hipMemsetAsync(bins, 0, (size_t)arrays * SORT_BINS * SORT_REP * sizeof(uint32_t), st);
-    const uint32_t grid = std::min<uint32_t>(blocks_for(nMax, RDX_BLOCK), 256u * 8u);
-    hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(RDX_BLOCK), 0, st, ps, mPtr, box, bins);
-    hipLaunchKernelGGL(k_sort_scan_tiles, dim3(arrays * SORT_TILES / 2u), dim3(256), 0, st, bins, sums);
-    hipLaunchKernelGGL(k_sort_scan_sums, dim3(arrays), dim3(1024), 0, st, sums);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(RDX_BLOCK), 0, st, ps, mPtr, box, bins, sums, permS, permE);
-}
 
 void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
                    uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,

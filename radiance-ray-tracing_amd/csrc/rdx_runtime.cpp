@@ -37,7 +37,7 @@ constexpr int RDX_MAX_DEVICES = 16;
 // option "sort" -1: scenes with at least this many inner BVH nodes are sorted.  Measured with the r02d engine (1080p x 4 spp; unsorted
 // / sorted): 10.4 M triangles 56.9 / 54.3 ms (the sorted hand-out makes the traversal launches 9 % faster, the eight sorts cost
 // 1.5 ms), Sponza-class 24.5 / 24.6 (break-even), sample1 13.3 / 15.4 (its rays are coherent as they come; the sort scrambles the
-// pixel order).  The first version of the sort (device-scope atomics, option value 2) cost 7.2 ms per frame and lost everywhere.
+// pixel order).
 constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 1u << 20;
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
@@ -114,8 +114,8 @@ struct Context {
     struct Group {
         PathStreams ps{};
         size_t cap = 0;
-        uint32_t* sortBins = nullptr;       // per-bounce ray sort: SORT_WORDS bin counters, and the two permutations
-        uint32_t* permS = nullptr; uint32_t* permE = nullptr; size_t permCap = 0;
+        uint32_t* sortBins = nullptr;       // per-bounce ray sort: histogram scratch (ray_sort_tiles_words()) and the permutation
+        uint32_t* permE = nullptr; size_t permCap = 0;
         uint32_t* dCounts = nullptr;        // [0] = paths generated, [d+1] = hits of bounce d, [64+d] / [128+d] ray counters
         uint32_t* hCounts = nullptr;        // pinned
         hipStream_t s0 = nullptr, s1 = nullptr;
@@ -172,11 +172,16 @@ inline const std::unique_ptr<AccelCache>& acc(const rdx_buffer_s* b) { return tl
 
 int fail(const char* fmt, ...)
 {
-    char buf[1024];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    g.err = buf;
+    // sized to the message (a compiler log of a user shader program runs to thousands of characters)
+    va_list ap, ap2; va_start(ap, fmt); va_copy(ap2, ap);
+    const int n = vsnprintf(nullptr, 0, fmt, ap); va_end(ap);
+    std::string buf((size_t)(n > 0 ? n : 0) + 1, '\0');
+    vsnprintf(&buf[0], buf.size(), fmt, ap2); va_end(ap2);
+    buf.resize((size_t)(n > 0 ? n : 0));
+    g.err = std::move(buf);
     return -1;
 }
+int fail_str(const std::string& text) { g.err = text; return -1; }
 #define HIP_OK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail("HIP error: '%s' returned %d (%s)", #expr, (int)_e, hipGetErrorString(_e)); } while (0)
 #define HIP_OKP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail("HIP error: '%s' returned %d (%s)", #expr, (int)_e, hipGetErrorString(_e)); return nullptr; } } while (0)
 
@@ -609,6 +614,16 @@ int scene_args(SceneArgs& sc)
     return 0;
 }
 
+// The status word the traversal kernels raise (bit 0: a wave hit its iteration bound) is tested and cleared after EVERY
+// synchronise that follows a traversal launch -- frames and the batch seams alike -- so that a raised bit is reported to
+// the call that caused it and never to the next one.
+bool take_status()
+{
+    if (!g.hStatus || !*static_cast<volatile uint32_t*>(g.hStatus)) return false;
+    *g.hStatus = 0;
+    return true;
+}
+
 struct StageTimer {
     // per-stage HIP-event timing (profiling mode): events are recorded around each launch and
     // resolved after the frame so that the stream is never drained in the middle
@@ -628,6 +643,7 @@ struct StageTimer {
         for (auto& s : spans) { float ms = 0; HIP_IGN(hipEventElapsedTime(&ms, s.a, s.b)); *s.dst += ms; }
         spans.clear(); used = 0;
     }
+    ~StageTimer() { for (hipEvent_t e : pool) HIP_IGN(hipEventDestroy(e)); }      // (worker threads of the multi-device mode end per frame)
 };
 thread_local StageTimer g_timer;
 
@@ -681,7 +697,6 @@ static void release_device_state()
         if (G.dCounts) HIP_IGN(hipFree(G.dCounts));
         if (G.hCounts) HIP_IGN(hipHostFree(G.hCounts));
         if (G.sortBins) HIP_IGN(hipFree(G.sortBins));
-        if (G.permS) HIP_IGN(hipFree(G.permS));
         if (G.permE) HIP_IGN(hipFree(G.permE));
         for (int i = 0; i < 64; ++i) { HIP_IGN(hipEventDestroy(G.evShade[i])); HIP_IGN(hipEventDestroy(G.evShadow[i])); }
         HIP_IGN(hipEventDestroy(G.evDone));
@@ -727,6 +742,8 @@ extern "C" int rdx_init_devices(uint32_t n, const int* ordinals)
     if (g_ndev > 1) return (uint32_t)g_ndev == n ? 0 : fail("rdx_init_devices: already initialised with %d devices", g_ndev);
     if (n == 1) return 0;
     if (!g0.buffers.empty()) return fail("rdx_init_devices must be called before any buffer is created");
+    for (auto& sh : g0.shaders)
+        if (sh->program) return fail("rdx_init_devices must be called before a user shader program is compiled (its code object is loaded on device 0 only)");
     int count = 0;
     HIP_OK(hipGetDeviceCount(&count));
     const bool virt = std::getenv("RDX_ALLOW_VIRTUAL_DEVICES") && std::atoi(std::getenv("RDX_ALLOW_VIRTUAL_DEVICES")) != 0;
@@ -751,7 +768,19 @@ extern "C" int rdx_init_devices(uint32_t n, const int* ordinals)
         std::string msg = g.err;
         tl_ctx = &g0; tl_dev = 0;
         HIP_IGN(hipSetDevice(g_phys[0]));
-        if (rc) return fail("rdx_init_devices: device %u (HIP %d): %s", d, g_phys[d], msg.c_str());
+        if (rc) {
+            // give back what was set up so far: contexts 1..d (the failing one holds whatever its init got to)
+            for (uint32_t e = 1; e <= d; ++e) {
+                tl_ctx = g_dev[e]; tl_dev = (int)e;
+                HIP_IGN(hipSetDevice(g_phys[e]));
+                g.initialized = true;          // release_device_state frees the non-null members
+                release_device_state();
+                tl_ctx = &g0; tl_dev = 0;
+                delete g_dev[e]; g_dev[e] = nullptr;
+            }
+            HIP_IGN(hipSetDevice(g_phys[0]));
+            return fail("rdx_init_devices: device %u (HIP %d): %s", d, g_phys[d], msg.c_str());
+        }
     }
     g_ndev = (int)n;
     return 0;
@@ -1022,7 +1051,7 @@ extern "C" rdx_buffer rdx_tlas_build(const rdx_instance* inst, uint32_t n)
 
 // radiance.cpp:428-448: raw dump of the TLAS buffer, size from header word 3
 // error text set from the library's other translation units (scene_obj.cpp)
-namespace rdx { int fail_text(const char* text) { return fail("%s", text); } }
+namespace rdx { int fail_text(const char* text) { return fail_str(text ? text : ""); } }
 
 // Side-car of a TLAS cache file: the cache itself stays the raw blob the reference writes
 // (radiance.cpp:428-448: totalBufferSize bytes, no header of its own), so files written by either side load on the
@@ -1281,7 +1310,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "pipeline")) { if (value < 0 || value > 1) return fail("pipeline must be 0 (staged) or 1 (paths)"); g.pathMode = (int)value; return 0; }
     if (!strcmp(name, "fuse")) { if (value < -1 || value > 1) return fail("fuse must be -1 (auto), 0 or 1"); g.fuse = (int)value; return 0; }
     if (!strcmp(name, "user_shader_local_size")) { if (value < 1 || value > 1024) return fail("user_shader_local_size must be 1..1024"); g.userLocalSize = (int)value; return 0; }
-    if (!strcmp(name, "sort")) { g.sortRays = value < 0 ? -1 : (value > 2 ? 2 : value); return 0; }      // 1 = counting sort on per-block LDS histograms, 2 = its predecessor on device-scope atomics
+    if (!strcmp(name, "sort")) { g.sortRays = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "textures")) { g.textures = value != 0; return 0; }
     if (!strcmp(name, "cull")) { g.cull = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
@@ -1337,7 +1366,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
         g.stats.pixels = nPix;
         HIP_OK(hipEventRecord(g.evA, g.stream));
         std::string err;
-        if (launch_user_shader(g.pipeline->program, g.stream, ptrs, (uint32_t)nPix, (uint32_t)g.userLocalSize, err)) return fail("%s", err.c_str());
+        if (launch_user_shader(g.pipeline->program, g.stream, ptrs, (uint32_t)nPix, (uint32_t)g.userLocalSize, err)) return fail_str(err);
         HIP_OK(hipEventRecord(g.evB, g.stream));
         HIP_OK(hipStreamSynchronize(g.stream));
         HIP_OK(hipEventElapsedTime(&g.stats.ms_total, g.evA, g.evB));
@@ -1485,19 +1514,16 @@ static int trace_rays_device(uint32_t width, uint32_t height)
                 if (sortOn) {
                     // per-bounce ray sort: the traversal launch below hands its rays out in (octant, Morton cell) order
                     if (G.permCap < n0) {
-                        if (G.permS) HIP_IGN(hipFree(G.permS));
                         if (G.permE) HIP_IGN(hipFree(G.permE));
-                        G.permS = G.permE = nullptr; G.permCap = 0;
-                        HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.permS), (size_t)n0 * 4));
+                        G.permE = nullptr; G.permCap = 0;
                         HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.permE), (size_t)n0 * 4));
                         G.permCap = n0;
                     }
-                    if (!G.sortBins) HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.sortBins), (size_t)std::max<uint32_t>(SORT_WORDS, ray_sort_tiles_words()) * 4));
+                    if (!G.sortBins) HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.sortBins), (size_t)ray_sort_tiles_words() * 4));
                     g_timer.begin(&g.stats.ms_sort, G.s0);
-                    if (g.sortRays == 2) launch_ray_sort(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permS, G.permE);
-                    else launch_ray_sort_tiles(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permE);
+                    launch_ray_sort_tiles(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permE);
                     g_timer.end(G.s0);
-                    ps.permS = (SORT_ONE_KEY || g.sortRays != 2) ? G.permE : G.permS; ps.permE = G.permE;
+                    ps.permS = G.permE; ps.permE = G.permE;
                 }
                 const PathStreams psShadow = ps;
                 // the compacted survivors become the live paths of the next bounce
@@ -1558,10 +1584,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
     if (visit) HIP_OK(hipMemcpyAsync(g.hVisit, g.dVisit, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, g.stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));          // clFinish (radiance.cpp:261)
-    if (g.hStatus && *g.hStatus) {
-        *g.hStatus = 0;
-        return fail("TraceRays: a traversal wave exceeded its iteration bound and gave up (internal error in the step selection); the frame is incomplete");
-    }
+    if (take_status()) return fail("TraceRays: a traversal wave exceeded its iteration bound and gave up (internal error in the step selection); the frame is incomplete");
     HIP_OK(hipEventElapsedTime(&g.stats.ms_total, g.evA, g.evB));
     g_timer.resolve();
     g.visitDepth = 0;
@@ -1613,6 +1636,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         c.groupsOpt = g0.groupsOpt; c.fuse = g0.fuse; c.pathMode = g0.pathMode; c.chunkPaths = g0.chunkPaths;
         c.countVisits = g0.countVisits; c.profiling = g0.profiling; c.inlineLeafRoots = g0.inlineLeafRoots; c.cull = g0.cull;
         c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap;
+        c.sortRays = g0.sortRays;
     }
     for (int d = 0; d < n; ++d) {
         tl_ctx = g_dev[d]; tl_dev = d;
@@ -1717,6 +1741,7 @@ extern "C" int rdx_trace_batch(rdx_buffer tlas, const float* o, const float* d, 
     HIP_OK(hipEventRecord(g.evB, g.stream));
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(g.stream));
+    if (take_status()) return fail("rdx_trace_batch: a traversal wave exceeded its iteration bound and gave up; the batch is incomplete");
     std::memset(&g.stats, 0, sizeof g.stats);
     HIP_OK(hipEventElapsedTime(&g.stats.ms_extend, g.evA, g.evB));      // kernel time of this batch
     if (n) HIP_OK(hipMemcpy(out, dH.p, (size_t)n * sizeof(rdx_hit), hipMemcpyDeviceToHost));

@@ -2,9 +2,11 @@
 //
 // tools/coop_stats.py shows where traverse_coop.h leaves lanes idle: a test step serves 62-64 lanes because any lane
 // may test any queued (ray, triangle) pair, but a node step only serves the lanes whose OWN ray holds a BLAS node at
-// that moment -- 29-33 of 64.  Here BLAS nodes get the treatment the triangles already have.  Nothing is culled by
-// the best t, so a pending (ray, node) pair is an independent work item whose only outputs are more such items and
-// queued triangle tests: all of a wave's pending BLAS nodes live in ONE LIFO pool in LDS and every pool step pops up
+// that moment -- 29-33 of 64.  Here BLAS nodes get the treatment the triangles already have.  A pending (ray, node)
+// pair is an independent work item whose only outputs are more such items, queued triangle tests and, through them,
+// the owner's best key (the exhaustive walk, CULL = false, never looks at the best t; the culled walk, CULL = true,
+// reads the owner's best t to drop items that cannot improve it -- a stale value only makes it drop less):
+// all of a wave's pending BLAS nodes live in ONE LIFO pool in LDS and every pool step pops up
 // to 64 of them, whichever rays they belong to.  The lane that processes an item reads the object-space ray of the
 // item from the owner's ray slot in LDS ("Rays in LDS" below), runs the two slab tests of the wide node with the
 // reference's decision rule, pushes inner children back, queues leaf triangles for the owner and adjusts the owner's
@@ -679,7 +681,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         // (not reached: with an empty pool one of the two top-level branches above is always taken)
         if (qTail != qHead) POOL_TEST();
     }
-    if (!finished && lane == 0 && A.status) atomicOr(A.status, 1u);       // the iteration bound was hit: the host reports an error
+    // the iteration bound was hit: the host reports an error.  (A plain system-scope store into the pinned host word: an
+    // atomic would need PCIe atomics, and nothing else is ever written there.)
+    if (!finished && lane == 0 && A.status) __hip_atomic_store(A.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef COOP_STATS
     if (lane < 8u) atomicAdd(&g_coop_state[lane], (unsigned long long)stState[lane]);
     if (lane < 8u) atomicAdd(&g_coop_cycles[lane], statC[lane]);

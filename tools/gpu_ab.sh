@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpu_pool_var.sh -- frame times of the default build and of every experiment build radiance-ray-tracing_amd/librdx_*.so
+# gpu_ab.sh -- frame times of the default build and of every experiment build radiance-ray-tracing_amd/librdx_*.so
 mkdir -p gpurun_out
 run() { for wl in sample1 sponza sanmiguel; do
     timeout -k 10 300 python bench.py --steps 6 --warmup 2 --workload $wl --also= --no-cpu-baseline --no-pmc --no-reference > gpurun_out/bv.json 2>gpurun_out/bv.err || { echo "bench failed"; tail -5 gpurun_out/bv.err; continue; }
