@@ -195,19 +195,21 @@ int         rdx_set_profiling(int on);
  * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
  * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
  * cross-checks), "user_shader_local_size" (work-group size of a user shader program's launch, default 64; the reference
- * launches with 1, radiance.cpp:250-259 -- results do not depend on it), "sort" (-1 (default) = automatic: on for scenes of >= 1 M inner BVH nodes; 1 / 0 = on / off; 2 = the first, atomics-based version: per-bounce ray sort -- the survivors of a bounce are handed to the
+ * launches with 1, radiance.cpp:250-259 -- results do not depend on it), "sort" (-1 (default) = automatic: on for scenes of >= 1 M inner BVH nodes; 1 / 0 = on / off: per-bounce ray sort -- the survivors of a bounce are handed to the
  * traversal launch in (Morton cell of the origin, direction octant) order, by an index permutation from a counting sort; the
  * path streams are not moved and no result depends on it), "textures" (0 (default) / 1.  The live reference shader has every texture read commented out (`uint4 tex =
  * 0.0f;//read_imageui(...)`, samples/shader.cl:379,411,421,445), so a material with a texture index renders with texel 0; that
  * is what 0 reproduces, bit for bit.  1 performs the commented-out read -- coord (uv.x, 1 - uv.y, texIdx), as the reference's
  * older shader2.cl:255-265 does live -- from the image array in slot 11 through the sampler in slot 12), "cull" (pool kernel: -1 (default) = automatic, 1 / 0 = on / off: closest-hit rays skip subtrees the ray enters
- * beyond the best t found so far, every ray skips leaves whose box it misses -- with a 2^-8 relative margin; results are
- * verified bit-identical to the reference's exhaustive walk, see kernels.hip "culled walk"; automatic = on for scenes with
- * at least 16 k inner BVH nodes), "top_flat" (1 (default) / 0: the pool kernel evaluates a top-level tree of <= 64 nodes all at once per
+ * beyond the best t found so far, every ray skips leaves whose box it misses -- only where a per-node normal cone proves the
+ * reference's fp32 intersection test well conditioned for that ray, with margins that cover its error: the result is the
+ * reference's exhaustive walk's, docs/CULLED_WALK.md has the proof; automatic = on for scenes with at least 1 M inner BVH
+ * nodes, where it pays), "group_instances" (1 (default) / 0: instances whose inverse matrices are bit-identical share one
+ * object-space ray and are walked concurrently, traverse_pool.h), "top_flat" (1 (default) / 0: the pool kernel evaluates a top-level tree of <= 64 nodes all at once per
  * ray instead of walking it), "inline_leaf_roots" (1 (default) / 0: ... and tests the triangles of single-leaf BLASes
  * right there), "pipeline" (0 = staged
- * wavefront: one launch per stage per bounce (default); 1 = whole paths -- camera ray to path end -- in one
- * persistent cooperative launch per sample chunk), "fuse" (1 / -1 = on (default), 0 = off:
+ * wavefront: one launch per stage per bounce; 1 = whole paths -- camera ray to path end -- in one persistent launch per
+ * sample chunk, the closest-hit shader called from the traversal waves; -1 (default) = automatic), "fuse" (1 / -1 = on (default), 0 = off:
  * trace the shadow rays of bounce d and the extend rays of bounce d+1 in one cooperative launch, which
  * halves the fixed ramp + tail cost per bounce), "groups" (0 (default) = automatic, 1..4: the samples of a chunk are
  * traced as that many independent groups on their own streams, each launching its share of the persistent grid, so

@@ -25,6 +25,8 @@ struct AccelView {                 // derived traversal layout (see rdx_types.h)
     uint32_t* status;              // device-visible status word (pinned host memory): bit 0 = a traversal wave hit its iteration bound
     uint32_t cull;                 // pool engine: culled walk (best-t culling of closest-hit rays, leaf-box test; kernels.hip)
     uint32_t kernel;               // 2 = wave-cooperative (default), 3 = wave-cooperative with a shared node pool, 1 = per-lane wide, 0 = reference order
+    uint32_t groupCount;           // pool engine: instances in the shared-transform group (rdx_runtime.cpp derive_accel), 0 = none
+    const uint32_t* groupBits;     // ... and their slots as a bitmap of 9 words in device memory (flat top level only: <= 256 instances)
 };
 
 // limits of the cooperative engines' packed words, shared by the kernels (traverse_coop.h) and the host's fallback rule

@@ -186,17 +186,67 @@ __device__ __forceinline__ bool slab_fast(const RayInst& R, f3 bmin, f3 bmax)
 // ---- culled walk (pool engine, option "cull") --------------------------------------------------------------------------
 // The reference's walk is exhaustive: it never compares a box with the best t found so far and never tests the box of a
 // leaf (radiance.cl:41-108,195-208).  Its RESULT, though, is the minimum of (t, instance slot, triangle slot) over the
-// triangles it tests and accepts (traverse_coop.h), and a triangle whose t cannot be smaller than the current best -- or
-// that the ray cannot touch at all -- never changes that minimum.  So, for a closest-hit ray, a subtree whose box the ray
-// enters beyond best_t, and for any ray a leaf whose box the ray misses, may be skipped.  In exact arithmetic that is
-// lossless; in fp32 the slab test and Moeller-Trumbore round differently, so both skips keep a margin of 2^-8 RELATIVE
-// (four orders of magnitude above the 2^-22 of the slab arithmetic; what it has to absorb is the error of a computed t or
-// barycentric of a badly conditioned -- grazing, sliver, far-away -- triangle).  This is not a proof: a triangle hit at
-// under ~0.1 degree whose computed t is off by more than 0.4 % could still be accepted by the reference and skipped here.
-// It is verified instead: bit-identical HitData and whole frames against the reference's own device code on every
-// config (tests/test_gpu_reference.py) and against the exhaustive kernels (options "cull" 0, "kernel" 2 / 1 / 0).
+// triangles it tests and ACCEPTS (traverse_coop.h), and a triangle the reference's Moeller-Trumbore cannot accept -- or can
+// accept only with a t that does not beat the current best -- never changes that minimum.  So a closest-hit ray may skip a
+// subtree whose box it enters beyond best_t, and any ray a leaf whose box it misses -- IF the fp32 intersection test is known
+// not to accept a triangle the exact ray stays clear of.  That is a statement about conditioning (DESIGN.md 4.1c has the proof):
+//
+//   if the reference accepts triangle T = (v0, e1, e2) for the ray (o, d) with the computed t~, then the point o + t~ d lies within
+//       R = 24 u |o - v0| / kappa + 3 u (t~ |d| + |e1| + |e2|),     kappa = |det~| / (|d| |e1| |e2|),  u = 2^-24
+//   of T.  kappa is, up to 5 u, sin(angle(e1, e2)) * |cos(angle(d, normal))|: small for slivers and for rays (nearly) IN the
+//   triangle's plane, where det is rounding noise and the reference accepts or rejects at random (tests/test_gpu_cull.py has
+//   such rays: a margin alone, however wide, is wrong for them).
+//
+// Hence the gate: every child descriptor of a wide node carries the NORMAL CONE of the triangles of that leaf / below that inner
+// child (rdx_types.h, derive_accel), and the child may be skipped only by rays that provably have kappa >= 2^-7 against all of
+// them (`safe`); then R <= 1.86e-4 * S with S >= |o - v| for every vertex in the child's box, and the skips keep a margin that covers R:
+//   leaf      skipped iff the slabs miss each other by more than max(2^-8 (|tFar| + n0), mabs),  mabs = 4e-4 * S1 * max|1/d_k|
+//   subtree   skipped iff it is entered beyond max(best_t (1 + 2^-8), best_t + mabs)              (S1 = L1 bound of S from the boxes)
+// (2^-8: what round 2 used alone; it still covers the slab arithmetic's own 2^-22.)  A ray that fails a child's gate treats that
+// child as the exhaustive walk does.  Verified on top: tests/test_gpu_cull.py, tests/test_gpu_reference.py (frames of configs 1-4 bit-identical).
 #define RDX_CULL_K 1.00390625f            // 1 + 2^-8
 #define RDX_CULL_M 0.00390625f            // 2^-8
+#define RDX_CULL_ABS 4.0e-4f              // >= 2.01 * (24 / kappa0 + 15.1) * 1.01 * u * 1.05 with kappa0 = 2^-7 (3.93e-4)
+
+// per-item constants of the gate (the ray's, not the child's)
+struct CullRay {
+    float sd;         // 127.5 (dx + dy + dz): the bias of the cone's axis bytes, times the direction
+    float dlen;       // |d|
+    float cabs;       // RDX_CULL_ABS * max |1 / d_k|
+};
+__device__ __forceinline__ CullRay cull_ray(const RayInst& R)
+{
+    CullRay C;
+    C.sd = (R.d.x + R.d.y + R.d.z) * 127.5f;
+    C.dlen = sqrtf(fmaf(R.d.x, R.d.x, fmaf(R.d.y, R.d.y, R.d.z * R.d.z)));
+    C.cabs = RDX_CULL_ABS * fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
+    return C;
+}
+struct CullGate {
+    bool safe;        // the ray is well conditioned against every triangle of the leaf / below the inner child
+    float mabs;       // absolute margin (in t) that covers the intersection test's error there
+};
+// (d0, d1): the child's descriptor with its normal cone (rdx_types.h); bmin / bmax: the child's box, which holds every vertex below it
+__device__ __forceinline__ CullGate cull_gate(const RayInst& R, const CullRay& C, uint32_t d0, uint32_t d1, bool isLeaf, f3 bmin, f3 bmax)
+{
+    CullGate G;
+#ifdef RDX_CULL_UNGATED          // timing experiment only (round 2's walk: the margin alone, wrong for rays in a triangle's plane)
+    G.safe = true; G.mabs = 0.0f; return G;
+#endif
+    const float bz = (float)(d1 & 0xffu), bx = (float)((d1 >> 8) & 0xffu), by = (float)((d1 >> 16) & 0xffu);
+    const float T = (float)(isLeaf ? (d0 >> WIDE_SLOT_BITS) : ((d1 >> 24) & 0x7fu));
+    const float dp = fmaf(R.d.x, bx, fmaf(R.d.y, by, fmaf(R.d.z, bz, -C.sd)));
+    G.safe = (T < 127.0f) & (fabsf(dp) >= T * C.dlen);
+    const float s1 = fmaxf(fabsf(bmin.x - R.o.x), fabsf(bmax.x - R.o.x)) + fmaxf(fabsf(bmin.y - R.o.y), fabsf(bmax.y - R.o.y)) +
+                     fmaxf(fabsf(bmin.z - R.o.z), fabsf(bmax.z - R.o.z));
+    G.mabs = C.cabs * s1;
+    return G;
+}
+// entry distance beyond which a child with gate G cannot matter, given the ray's bound `tlim` (best t so far, or tmax)
+__device__ __forceinline__ float cull_limit(const CullGate& G, float tlim)
+{
+    return G.safe ? fmaxf(tlim * RDX_CULL_K, tlim + G.mabs) : __builtin_inff();
+}
 
 // slab_fast that also reports the entry distance max(tNear, 0) its decision was made with
 __device__ __forceinline__ bool slab_fast_t(const RayInst& R, f3 bmin, f3 bmax, float& tn)
@@ -222,34 +272,23 @@ __device__ __forceinline__ bool slab_fast_t(const RayInst& R, f3 bmin, f3 bmax, 
     return tFar > tn;
 }
 
-// may the ray touch a triangle inside this (leaf) box at a distance that still matters?  Conservative: `false` only when
-// the slabs miss each other by more than the margin, or the box is entered beyond cullT.  Rays with a (nearly) zero
-// direction component are never refused.
-__device__ __forceinline__ bool leaf_box_maybe(const RayInst& R, f3 bmin, f3 bmax, float cullT)
-{
-    if (R.exactOnly) return true;
-    const f3 tA = (bmin - R.o) * R.rcp, tB = (bmax - R.o) * R.rcp;
-    const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
-    const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
-    const float n0 = fmaxf(tNear, 0.0f);
-    const float m = RDX_CULL_M * (fabsf(tFar) + n0) + 1e-30f;
-    return !(n0 - tFar > m) && !(n0 > cullT);
-}
-
 // One child of a wide node in the culled walk, leaf or inner, in one straight-line evaluation of the slabs (the two kinds
 // differ in the margin and in what "undecided" means, not in the arithmetic -- and a wave's 64 items are a mix of both):
-//   leaf  -> leaf_box_maybe(R, bmin, bmax, cullT)
-//   inner -> slab_fast_t(R, bmin, bmax, tn) && !(tn > cullT)
-// with exactly their decisions; tn is the entry distance (inner children only).
-__device__ __forceinline__ bool cull_child(const RayInst& R, f3 bmin, f3 bmax, bool isLeaf, float cullT, float& tn)
+//   leaf  -> may the ray touch a triangle inside this box at a distance that still matters?  `false` only when the gate is
+//            open and the slabs miss each other by more than the margin, or the box is entered beyond cullT
+//   inner -> the reference's own decision (slab_fast_t) && !(tn > cullT)
+// tlim = best t so far or tmax; tn is the entry distance (inner children only).  Rays with a (nearly) zero direction component
+// never skip a leaf.
+__device__ __forceinline__ bool cull_child(const RayInst& R, f3 bmin, f3 bmax, bool isLeaf, const CullGate& G, float tlim, float& tn)
 {
     const f3 tA = (bmin - R.o) * R.rcp, tB = (bmax - R.o) * R.rcp;
     const float tNear = fmaxf(fmaxf(fminf(tA.x, tB.x), fminf(tA.y, tB.y)), fminf(tA.z, tB.z));
     const float tFar = fminf(fminf(fmaxf(tA.x, tB.x), fmaxf(tA.y, tB.y)), fmaxf(tA.z, tB.z));
     const float n0 = fmaxf(tNear, 0.0f);
-    const float m = (isLeaf ? RDX_CULL_M : 4.8e-7f) * (fabsf(tFar) + n0) + 1e-30f;
+    const float rel = (isLeaf ? RDX_CULL_M : 4.8e-7f) * (fabsf(tFar) + n0) + 1e-30f;
+    const float m = isLeaf ? fmaxf(rel, G.mabs) : rel;
     const float diff = tFar - n0;
-    const bool hit = diff > m, miss = -diff > m;
+    const bool hit = diff > m, miss = (-diff > m) & (G.safe | !isLeaf);
     bool res = isLeaf ? !miss : hit;
     tn = n0;
     if (!isLeaf && (R.exactOnly || !(hit || miss))) {
@@ -263,7 +302,7 @@ __device__ __forceinline__ bool cull_child(const RayInst& R, f3 bmin, f3 bmax, b
         res = eFar > tn;
     }
     if (isLeaf && R.exactOnly) return true;
-    return res && !(tn > cullT);
+    return res && !(tn > cull_limit(G, tlim));
 }
 
 struct Best {
@@ -337,7 +376,7 @@ __device__ __forceinline__ void traverse_wide(const AccelView& A, f3 o, f3 d, fl
                 const uint32_t d0 = f2u(bmin.w), d1 = f2u(bmax.w);
                 uint32_t item = RDX_MISS;
                 if (d1 & WIDE_LEAF) {
-                    uint32_t cnt = d1 & 0x7fffffffu, st = d0;
+                    uint32_t cnt = wide_count(d1), st = wide_slot(d0);
                     while (cnt > 8u) { stack[sp * stride] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }   // rare: oversized leaf
                     if (cnt) item = leaf_item(st, cnt);
                 } else if (slab_fast(R, mk3(bmin.x, bmin.y, bmin.z), mk3(bmax.x, bmax.y, bmax.z))) {
@@ -385,7 +424,7 @@ __device__ __forceinline__ void traverse_wide(const AccelView& A, f3 o, f3 d, fl
             R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
             const uint4 rd = *reinterpret_cast<const uint4*>(ip + 9);
             if (rd.y & WIDE_LEAF) {
-                uint32_t cnt = rd.y & 0x7fffffffu, st = rd.x;
+                uint32_t cnt = wide_count(rd.y), st = wide_slot(rd.x);
                 while (cnt > 8u) { stack[sp * stride] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }
                 if (cnt) { cur = leaf_item(st, cnt); continue; }
             } else {
@@ -1021,6 +1060,24 @@ k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
 // path streams shrink to the few values that must survive a shadow walk (indexed by path, no compaction).
 // Arithmetic per value is that of the staged kernels (k_generate / k_shade / k_shadow), so frames are
 // bit-identical to the staged pipeline.
+// The closest-hit shader as a real function call: inlined into the persistent traversal loop its ~100 live registers add to
+// the loop's own (round 2: 199-211 VGPRs, 2 waves per SIMD, 2.3x slower than the staged pipeline); called, the loop's state is
+// saved around the call and the kernel needs max(loop, shader) registers.
+struct ShadeCall { f3 o, d; float t, b1, b2; uint32_t triSlot, inst, frameID, pixel, depth, more; };
+__device__ __attribute__((noinline)) void shade_call(const AccelView* A, const SceneArgs* sc, const ShadeCall* in, Payload* out)
+{
+    Payload p;
+    p.hit = false; p.wantsShadowRay = false;
+    p.color = mk3(0.f, 0.f, 0.f); p.colorOccluded = p.color;
+    p.nextFactor = mk3(1.f, 1.f, 1.f);
+    p.nextRayOrigin = in->o; p.nextRayDirection = in->d; p.shadowOrigin = in->o;
+    const SceneView sv{sc->scene, sc->meshInfo, sc->indexData, sc->uvData, sc->normalData, sc->materials, sc->tex};
+    HitInfo h;
+    fill_hit_info(*A, in->inst, in->o, in->d, in->t, in->b1, in->b2, A->tris[in->triSlot].primID, h);
+    callHit((int)A->insts[in->inst].SBTOffset + 1, p, h, sv, in->d, in->frameID, in->pixel, in->depth, in->more != 0u);
+    *out = p;
+}
+
 struct PathPolicy {
     AccelView A; SceneArgs sc; CameraArgs C; PathStreams ps; const uint32_t* owned;
     uint32_t nPixels, sampleBegin, totalSamples, maxDepth, sampleBase;
@@ -1089,14 +1146,8 @@ struct PathPolicy {
     {
         const float4 thr = ps.thr[i], col = ps.col[i];
         Payload p;
-        p.hit = false; p.wantsShadowRay = false;
-        p.color = mk3(0.f, 0.f, 0.f); p.colorOccluded = p.color;
-        p.nextFactor = mk3(1.f, 1.f, 1.f);
-        p.nextRayOrigin = o; p.nextRayDirection = d; p.shadowOrigin = o;
-        const SceneView sv{sc.scene, sc.meshInfo, sc.indexData, sc.uvData, sc.normalData, sc.materials, sc.tex};
-        HitInfo h;
-        fill_hit_info(A, st.inst, o, d, st.t, st.b1, st.b2, A.tris[st.triSlot].primID, h);
-        callHit((int)A.insts[st.inst].SBTOffset + 1, p, h, sv, d, st.frameID, st.pixel, st.depth, st.depth + 1 < maxDepth);
+        const ShadeCall in{o, d, st.t, st.b1, st.b2, st.triSlot, st.inst, st.frameID, st.pixel, st.depth, st.depth + 1 < maxDepth ? 1u : 0u};
+        shade_call(&A, &sc, &in, &p);
         const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
         if (!p.hit) {                // no closest-hit shader bound for this row: the raygen loop sees a miss
             end_path(i, st, st.depth == 0 ? p.color : Cc);
@@ -1117,16 +1168,18 @@ struct PathPolicy {
     }
 };
 
-__global__ void __launch_bounds__(RDX_BLOCK)
-k_path_coop(AccelView A, SceneArgs sc, CameraArgs C, PathStreams ps, const uint32_t* __restrict__ owned, uint32_t nPixels,
+// whole paths on the shared-node-pool engine (traverse_pool.h): option "pipeline" 1
+template <bool INL, bool CULL>
+__global__ void __launch_bounds__(RDX_BLOCK, 5)
+k_path_pool(AccelView A, SceneArgs sc, CameraArgs C, PathStreams ps, const uint32_t* __restrict__ owned, uint32_t nPixels,
             uint32_t sampleBegin, uint32_t sampleCount, uint32_t totalSamples, uint32_t maxDepth, uint32_t sampleBase,
             uint32_t* __restrict__ counter, unsigned long long* __restrict__ tally, float tmin, float tmax)
 {
     const float* ld = sc.scene->lights[0].direction;
     PathPolicy pol{A, sc, C, ps, owned, nPixels, sampleBegin, totalSamples, maxDepth, sampleBase,
                    normalize3(mk3(-ld[0], -ld[1], -ld[2])), tally};
-    traverse_coop<3>(A, pol, nPixels * sampleCount, counter, tmin, tmax,
-                     s_stack + (threadIdx.x >> 6) * coop_words_per_wave(A.coopNeed), A.coopNeed);
+    traverse_pool<3, INL, CULL>(A, pol, nPixels * sampleCount, counter, tmin, tmax,
+                                s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
 struct BatchPolicy {
@@ -1413,9 +1466,9 @@ void launch_path(hipStream_t st, const AccelView& av, const SceneArgs& sc, const
 {
     const uint64_t n = (uint64_t)nPixels * sampleCount;
     if (!n) return;
-    size_t lds; const uint32_t th = coop_threads(av.coopNeed, lds);
-    hipLaunchKernelGGL(k_path_coop, dim3(coop_blocks((uint32_t)n, th, lds)), dim3(th), lds, st, av, sc, cam, ps, owned, nPixels,
-                       sampleBegin, sampleCount, totalSamples, maxDepth, sampleBase, counter, tally, tmin, tmax);
+    size_t lds; const uint32_t th = coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), lds, 5);      // (the caller checks av.kernel == 3)
+    RDX_POOL_LAUNCH(k_path_pool, dim3(coop_blocks((uint32_t)n, th, lds, 5)), av, sc, cam, ps, owned, nPixels, sampleBegin, sampleCount,
+                    totalSamples, maxDepth, sampleBase, counter, tally, tmin, tmax);
 }
 
 void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* owned, uint32_t nPixels, uint32_t sampleBegin,

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -39,6 +40,7 @@ constexpr int RDX_MAX_DEVICES = 16;
 // 1.5 ms), Sponza-class 24.5 / 24.6 (break-even), sample1 13.3 / 15.4 (its rays are coherent as they come; the sort scrambles the
 // pixel order).
 constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 1u << 20;
+constexpr uint32_t RDX_CULL_AUTO_MIN_WIDE = 1u << 20;      // option "cull" -1: scenes with at least this many inner BVH nodes take the culled walk
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
     DNode* tnodes = nullptr; DNode* ctnodes = nullptr; DInst* insts = nullptr; DNode* bnodes = nullptr; DTri* tris = nullptr;
@@ -55,8 +57,12 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     uint32_t topFlat = 0, topFlatNeed = 1; // pool engine: number of top-level nodes if they are few enough (<= 64) to be evaluated
                                         // all at once per ray instead of walked, and the instance-mask entries that can then pile up
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
+    uint32_t* groupBits = nullptr;     // pool engine: instance slots of the shared-transform group (bitmap, 9 words on the device), see derive_accel
+    uint32_t groupCount = 0;
     void release()
     {
+        if (groupBits) HIP_IGN(hipFree(groupBits));
+        groupBits = nullptr;
         if (tnodes) HIP_IGN(hipFree(tnodes));
         if (ctnodes) HIP_IGN(hipFree(ctnodes));
         if (insts) HIP_IGN(hipFree(insts));
@@ -139,13 +145,14 @@ struct Context {
     int64_t chunkPaths = 16ll << 20;
     bool countVisits = false, profiling = false;
     int inlineLeafRoots = 1;                // pool engine: single-leaf BLASes handled in the flat top-level step (option "inline_leaf_roots")
-    int cull = -1;                          // pool engine: culled walk (option "cull"): 1 on, 0 off, -1 = on for scenes of >= 16 k inner nodes
+    int cull = -1;                          // pool engine: culled walk (option "cull"): 1 on, 0 off, -1 = on for scenes of >= 1 M inner nodes
     int textures = 0;                       // option "textures": 1 = the stock shader samples the bound image array
     std::vector<std::unique_ptr<rdx_sampler_s>> samplers;
     std::string shaderInclude;              // -I for user shader programs (rdx_shader_include_path; the reference's SHADER_LIB_PATH)
     int userLocalSize = 64;                 // option "user_shader_local_size": work-group size of a user program's launch (the reference uses 1)
     int sortRays = -1;                      // option "sort": per-bounce ray sort: 1 on, 0 off, -1 automatic
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
+    int groupInstances = 1;                 // pool engine: instances with bit-identical inverse matrices share one ray slot (option "group_instances")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
     rdx_trace_stats stats{};
@@ -211,6 +218,81 @@ uint32_t blas_need(const BlobNode* nodes, uint32_t idx)
     return ret;
 }
 
+// Cone of lines around the normals of a set of triangles + their worst shape; see DESIGN.md 4.1c for what the culled walk
+// proves from it.  kappa0 = 2^-7: the culled walk skips a subtree / a leaf only for rays that make at least asin(kappa0 / q)
+// with the plane of every triangle below the node.
+struct NormalCone {
+    double a[3] = {0, 0, 0};       // axis (unit) -- valid when n > 0
+    double alpha = 0;              // half-angle: every normal line is within alpha of the axis line
+    double q = 1;                  // min over the triangles of sin(angle(e1, e2))
+    bool never = false;            // degenerate triangle, or the normals do not fit a cone of < 90 degrees
+    uint32_t n = 0;
+    static double ang(const double* x, const double* y)      // angle between two LINES
+    {
+        const double c = std::fabs(x[0] * y[0] + x[1] * y[1] + x[2] * y[2]);
+        return std::acos(std::min(1.0, c));
+    }
+    void add_normal(const double* nn, double a1)
+    {
+        if (n == 0) { a[0] = nn[0]; a[1] = nn[1]; a[2] = nn[2]; alpha = a1; n = 1; return; }
+        NormalCone o; o.a[0] = nn[0]; o.a[1] = nn[1]; o.a[2] = nn[2]; o.alpha = a1; o.n = 1;
+        merge(o);
+    }
+    void add_triangle(const DTri& t)
+    {
+        const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+        const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double lc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        if (!(lc > 0) || !(l1 > 0) || !(l2 > 0) || !std::isfinite(lc) || !std::isfinite(l1 * l2)) { never = true; return; }
+        q = std::min(q, lc / (l1 * l2));
+        const double nn[3] = {c[0] / lc, c[1] / lc, c[2] / lc};
+        add_normal(nn, 0.0);
+    }
+    void merge(const NormalCone& o)
+    {
+        never = never || o.never; q = std::min(q, o.q);
+        if (o.n == 0) return;
+        if (n == 0) { a[0] = o.a[0]; a[1] = o.a[1]; a[2] = o.a[2]; alpha = o.alpha; n = o.n; return; }
+        const double sgn = (a[0] * o.a[0] + a[1] * o.a[1] + a[2] * o.a[2]) < 0 ? -1.0 : 1.0;
+        const double gam = ang(a, o.a);
+        n += o.n;
+        if (gam + o.alpha <= alpha) return;                                        // o inside this cone
+        if (gam + alpha <= o.alpha) { a[0] = o.a[0]; a[1] = o.a[1]; a[2] = o.a[2]; alpha = o.alpha; return; }
+        // smallest cone around both: axis between the two, rotated from a towards o by (gam + o.alpha - alpha) / 2
+        const double na = (gam + alpha + o.alpha) / 2;
+        const double w = gam > 1e-12 ? (na - alpha) / gam : 0.5;
+        double m[3] = {a[0] * (1 - w) + sgn * o.a[0] * w, a[1] * (1 - w) + sgn * o.a[1] * w, a[2] * (1 - w) + sgn * o.a[2] * w};
+        const double lm = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        if (!(lm > 1e-9)) { never = true; return; }
+        for (int k = 0; k < 3; ++k) m[k] /= lm;
+        // (the linear blend is not the exact bisecting rotation: take the half-angle from the blended axis itself)
+        const double sgn_o[3] = {sgn * o.a[0], sgn * o.a[1], sgn * o.a[2]};
+        alpha = std::max(ang(m, a) + alpha, ang(m, sgn_o) + o.alpha);
+        a[0] = m[0]; a[1] = m[1]; a[2] = m[2];
+    }
+    // x | y << 8 | z << 16 | T << 24 (T: 7 bits, rdx_types.h wide_desc): a ray may be culled against this leaf / subtree only if
+    // |d^ . a'| >= T / 127 with a' = (b - 127.5) / 127 the quantised axis.  Derivation: every normal line is within
+    // alpha + eq of a' (eq: quantisation), so the ray makes >= asin|d^ . a'^| - (alpha + eq) with every triangle's plane; that must be
+    // >= asin(kappa0 / q).  |a'| is within 0.7 % of 1, which the factor 1.0075 covers, fp32 evaluation another 1e-5.
+    uint32_t pack() const
+    {
+        const double kappa0 = 1.0 / 128.0, eq = 0.0085;
+        uint32_t T = WIDE_CONE_NEVER;
+        uint32_t b[3] = {128, 128, 128};
+        if (!never && n > 0 && q > kappa0 && alpha + eq < 1.5) {
+            const double need = std::asin(std::min(1.0, kappa0 / q)) + alpha + eq;     // angle the ray must make with the axis PLANE
+            if (need < 1.55) {
+                const double thr = std::sin(need) * 1.0075 * 1.00002;
+                const double t8 = std::ceil(thr * 127.0) + 1.0;
+                if (t8 <= 126.0) T = (uint32_t)t8;
+            }
+            for (int k = 0; k < 3; ++k) b[k] = (uint32_t)std::min(255.0, std::max(0.0, std::floor(127.5 + 127.0 * a[k] + 0.5)));
+        }
+        return b[0] | (b[1] << 8) | (b[2] << 16) | (T << 24);
+    }
+};
+
 int derive_accel(rdx_buffer_s* tb)
 {
     if (acc(tb) && acc(tb)->version == tb->version) return 0;
@@ -258,7 +340,9 @@ int derive_accel(rdx_buffer_s* tb)
     std::vector<DTri> dTri;
     std::vector<DWide> dW;
     std::vector<DInst> dI(nInst);
-    struct BlasInfo { uint32_t nodeBase; uint32_t need; uint32_t coopNeed; uint32_t anyNeed; uint32_t triBase; uint32_t rootDesc0, rootDesc1; float rootMin[3], rootMax[3]; };
+    struct BlasInfo { uint32_t nodeBase; uint32_t need; uint32_t coopNeed; uint32_t anyNeed; uint32_t triBase; uint32_t rootDesc0, rootDesc1; float rootMin[3], rootMax[3];
+                      uint32_t nTris; uint32_t users; };
+    bool hugeLeaf = false;                  // a leaf of more triangles than the wide layout's count field holds
     bool coopOK = nInst <= RDX_COOP_MAX_INSTANCES;
     bool sbtOffsets = false;
     uint32_t maxLeafChunks = 0;             // extra stack entries an oversized (> 8 triangle) leaf can push
@@ -316,8 +400,8 @@ int derive_accel(rdx_buffer_s* tb)
                 const float* v0 = bv + 4 * (size_t)t.idx0; const float* v1 = bv + 4 * (size_t)t.idx1; const float* v2 = bv + 4 * (size_t)t.idx2;
                 DTri& d = dTri[triBase + i];
                 d.v0[0] = v0[0]; d.v0[1] = v0[1]; d.v0[2] = v0[2]; d.primID = t.primID;
-                d.e1[0] = v1[0] - v0[0]; d.e1[1] = v1[1] - v0[1]; d.e1[2] = v1[2] - v0[2]; d._p0 = 0;   // radiance.cl:215
-                d.e2[0] = v2[0] - v0[0]; d.e2[1] = v2[1] - v0[1]; d.e2[2] = v2[2] - v0[2]; d._p1 = 0;   // radiance.cl:216
+                d.e1[0] = v1[0] - v0[0]; d.e1[1] = v1[1] - v0[1]; d.e1[2] = v1[2] - v0[2]; d._p0 = 0xffffffffu;   // radiance.cl:215; _p0: see "shared-transform group"
+                d.e2[0] = v2[0] - v0[0]; d.e2[1] = v2[1] - v0[1]; d.e2[2] = v2[2] - v0[2]; d._p1 = triBase;       // radiance.cl:216; _p1: first triangle slot of this BLAS
             }
             // wide layout: one record per inner node, numbered in the same DFS pre-order
             const uint32_t wideBase = (uint32_t)dW.size();
@@ -325,11 +409,25 @@ int derive_accel(rdx_buffer_s* tb)
             uint32_t nInner = 0;
             for (uint32_t i = 0; i < nNodes; ++i) if (!(bn[i].w0 & LEAF_BIT)) wideIdx[i] = nInner++;
             if ((uint64_t)wideBase + nInner >= (1u << 30)) return fail("too many BVH nodes for 30-bit references");
+            std::vector<NormalCone> cone(nNodes);
             auto desc = [&](uint32_t c, uint32_t& d0, uint32_t& d1) {
-                if (bn[c].w0 & LEAF_BIT) { d0 = bn[c].w1 + triBase; d1 = WIDE_LEAF | (bn[c].w2 == TYPE_TRIG ? (bn[c].w0 & 0x7fffffffu) : 0u); }
-                else { d0 = wideBase + wideIdx[c]; d1 = 0; }
+                if (bn[c].w0 & LEAF_BIT) {
+                    const uint32_t cnt = bn[c].w2 == TYPE_TRIG ? (bn[c].w0 & 0x7fffffffu) : 0u;
+                    if (cnt > WIDE_MAX_LEAF_TRIS) hugeLeaf = true;
+                    wide_desc(true, bn[c].w1 + triBase, std::min(cnt, (uint32_t)WIDE_MAX_LEAF_TRIS), cone[c].pack(), d0, d1);
+                } else wide_desc(false, wideBase + wideIdx[c], 0u, cone[c].pack(), d0, d1);
             };
             dW.resize(wideBase + nInner);
+            // Normal cones (culled walk, kernels.hip): for every node the cone of LINES that holds the normals of all triangles
+            // below it -- axis, half-angle alpha -- and the worst triangle shape q = min sin(angle(e1, e2)).  Bottom-up (children
+            // have larger indices); computed in double from the fp32 edge vectors the intersection test uses.
+            for (uint32_t i = nNodes; i-- > 0;) {
+                NormalCone& c = cone[i];
+                if (bn[i].w0 & LEAF_BIT) {
+                    const uint32_t cnt = bn[i].w2 == TYPE_TRIG ? (bn[i].w0 & 0x7fffffffu) : 0u;
+                    for (uint32_t t = 0; t < cnt; ++t) c.add_triangle(dTri[triBase + bn[i].w1 + t]);
+                } else { c = cone[bn[i].w0]; c.merge(cone[bn[i].w1]); }
+            }
             // Stack need of the wide walk: a leaf child is queued, never pushed; of two inner children one is followed
             // and the other pushed.  The visiting order is free, so the child with the SMALLER need goes
             // into the "followed" (left) half of the record: need = max(1 + smaller, larger) instead of
@@ -360,8 +458,10 @@ int derive_accel(rdx_buffer_s* tb)
             if (nTris > RDX_COOP_MAX_BLAS_TRIS) coopOK = false;
             desc(0, info.rootDesc0, info.rootDesc1);
             for (int k = 0; k < 3; ++k) { info.rootMin[k] = bn[0].bottom[k]; info.rootMax[k] = bn[0].top[k]; }
+            info.nTris = nTris; info.users = 0;
             it = blasAt.emplace(bi.instanceOffset, info).first;
         }
+        it->second.users++;
         DInst& d = dI[k];
         std::memset(&d, 0, sizeof d);
         std::memcpy(d.fwd, bi.m, 64);
@@ -396,6 +496,33 @@ int derive_accel(rdx_buffer_s* tb)
             d.worldMin[3] = usable ? (float)(64.0 * 5.97e-8 * 4.0 * kappa) : -1.0f;
             d.worldMax[3] = (float)ext;
         }
+    }
+    // Shared-transform group (pool engine, flat top level).  The object-space ray of an instance is inverse(object->world) applied
+    // to the world ray with the reference's expressions (radiance.cl:161-169) -- a function of the inverse matrix's BITS and the
+    // ray alone.  Instances whose inverse matrices are bit-identical (a loader that puts every mesh of an OBJ under one node:
+    // all identity, tools/sceneBuilder.cpp:287-315; every scene of this repository's bench) therefore share ONE object-space
+    // ray: a wave lane writes it to its LDS ray slot once and enters all of them without waiting for one instance's subtree and
+    // queued tests to drain before the next (traverse_pool.h).  The instance slot a candidate belongs to then cannot come from
+    // the ray slot; it is kept in the triangle record (DTri._p0), which needs the BLAS to belong to exactly one instance.
+    // The largest such set of instances (>= 2, inner-node roots only) is the group.
+    uint32_t groupBits[8] = {0, 0, 0, 0, 0, 0, 0, 0}, groupCount = 0;
+    if (nInst <= 256) {
+        std::map<std::array<uint32_t, 16>, std::vector<uint32_t>> byInv;
+        for (uint32_t k = 0; k < nInst; ++k) {
+            const BlasInfo& bi = blasAt[binst[k].instanceOffset];
+            if (bi.users != 1 || (dI[k].rootDesc1 & WIDE_LEAF)) continue;
+            std::array<uint32_t, 16> key;
+            std::memcpy(key.data(), dI[k].inv, 64);
+            byInv[key].push_back(k);
+        }
+        const std::vector<uint32_t>* best = nullptr;
+        for (auto& kv : byInv) if (kv.second.size() >= 2 && (!best || kv.second.size() > best->size())) best = &kv.second;
+        if (best)
+            for (uint32_t k : *best) {
+                groupBits[k >> 5] |= 1u << (k & 31u); ++groupCount;
+                const BlasInfo& bi = blasAt[binst[k].instanceOffset];
+                for (uint32_t t = 0; t < bi.nTris; ++t) dTri[bi.triBase + t]._p0 = k;
+            }
     }
     // stack need: TLAS part
     // (cooperative kernel: the instances of a top-level leaf are pushed as 16-bit masks, one entry per 16 instances,
@@ -440,7 +567,7 @@ int derive_accel(rdx_buffer_s* tb)
             if (!(tnodes[i].w0 & LEAF_BIT)) continue;
             for (uint32_t k = 0; k < (tnodes[i].w0 & 0x7fffffffu); ++k) {
                 const DInst& di = dI[tnodes[i].w1 + k];
-                if ((di.rootDesc1 & WIDE_LEAF) && (di.rootDesc1 & 0x7fffffffu) <= 8u) { dT[i].w3 = 1; ac->leafRoots = true; }
+                if ((di.rootDesc1 & WIDE_LEAF) && wide_count(di.rootDesc1) <= 8u) { dT[i].w3 = 1; ac->leafRoots = true; }
             }
         }
         ac->nInst = nInst;
@@ -450,7 +577,8 @@ int derive_accel(rdx_buffer_s* tb)
     ac->blasNeed = maxBlasCoop;
     ac->blasNeedAny = maxBlasAny;
     for (int k = 0; k < 3; ++k) { ac->sceneLo[k] = tnodes[0].bottom[k]; ac->sceneHi[k] = tnodes[0].top[k]; }
-    ac->sbtOffsets = sbtOffsets;
+    ac->sbtOffsets = sbtOffsets || hugeLeaf;      // (either way: the reference-order kernel, which reads the blob's own node layout)
+    ac->groupCount = groupCount;
     ac->nWide = (uint32_t)dW.size();
     // per-lane kernels: [need][64 lanes] words of LDS per wave, 64 KB at most
     if (ac->stackNeed > 250) return fail("BVH too deep for the LDS traversal stack: %u entries per ray needed, 250 available", ac->stackNeed);
@@ -467,6 +595,10 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->bnodes, dB));
     HIP_OK(up(ac->tris, dTri));
     HIP_OK(up(ac->wide, dW));
+    {
+        const std::vector<uint32_t> gb{groupBits[0], groupBits[1], groupBits[2], groupBits[3], groupBits[4], groupBits[5], groupBits[6], groupBits[7], 0u};
+        HIP_OK(up(ac->groupBits, gb));
+    }
     // packed-word limits of the cooperative engines (kernels.h) and their LDS footprint; beyond them the per-lane wide kernel runs
     ac->coopOK = coopOK && dTri.size() <= RDX_COOP_MAX_TRI_SLOTS - 1u && dW.size() < RDX_COOP_MAX_WIDE &&
                  coop_lds_words(ac->coopNeed) <= RDX_LDS_WORDS_PER_WAVE_MAX &&
@@ -489,14 +621,17 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.kernel = acc(tb)->sbtOffsets ? 0u : (g.kernel >= 2 && !acc(tb)->coopOK) ? 1u : (uint32_t)g.kernel;
     v.stackNeed = acc(tb)->stackNeed;
     v.coopNeed = acc(tb)->coopNeed;
-    // culled walk: measured +11 % (262 k triangles) / +26 % (10.4 M) frame rate, -2 % on the 20 k-triangle sample1 scene, whose
-    // leaves are cheap and whose rays mostly end in quads handled inside the top-level step -- hence the size rule
-    v.cull = (v.kernel == 3 && (g.cull > 0 || (g.cull < 0 && acc(tb)->nWide >= 16384u))) ? 1u : 0u;
+    // culled walk (docs/CULLED_WALK.md): with the conditioning gate that makes it exact it pays on the scene whose BVH lives in HBM
+    // (10.4 M triangles: 66.2 vs 72.1 ms) and not on scenes that fit the caches (Sponza-class: 25.9 vs 25.3 ms exhaustive -- the
+    // gate's ~45 vector instructions per node cost what the skipped triangle tests save) -- hence the size rule
+    v.cull = (v.kernel == 3 && (g.cull > 0 || (g.cull < 0 && acc(tb)->nWide >= RDX_CULL_AUTO_MIN_WIDE))) ? 1u : 0u;
     v.topNeed = acc(tb)->topNeed; v.blasNeed = v.cull ? acc(tb)->blasNeedAny : acc(tb)->blasNeed;
     v.topFlat = g.topFlat ? acc(tb)->topFlat : 0u;
     v.numInsts = acc(tb)->nInst;
     if (v.topFlat) v.topNeed = acc(tb)->topFlatNeed;          // flat top level: words per lane of the pending-instance bitmap
     v.leafRoots = (v.topFlat && g.inlineLeafRoots && acc(tb)->leafRoots) ? 1u : 0u;
+    v.groupCount = (v.topFlat && g.groupInstances) ? acc(tb)->groupCount : 0u;
+    v.groupBits = acc(tb)->groupBits;
     return v;
 }
 
@@ -1314,6 +1449,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "textures")) { g.textures = value != 0; return 0; }
     if (!strcmp(name, "cull")) { g.cull = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
+    if (!strcmp(name, "group_instances")) { g.groupInstances = value != 0; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
@@ -1445,8 +1581,8 @@ static int trace_rays_device(uint32_t width, uint32_t height)
         }
         HIP_OK(hipEventRecord(g.evChunk, g.stream));          // everything before this chunk (previous accumulate) is done first
 
-        if (g.pathMode == 1 && !visit && av.kernel >= 2 && maxDepth > 0) {
-            // ---- whole paths in one persistent launch (k_path_coop) + accumulate ----
+        if (g.pathMode == 1 && !visit && av.kernel == 3 && maxDepth > 0) {
+            // ---- whole paths in one persistent launch (k_path_pool) + accumulate ----
             Context::Group& G = g.groups[0];
             const uint32_t n0 = sc_n * P;
             if (ensure_group(G, n0)) return -1;
@@ -1635,7 +1771,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         c.nslots = g0.nslots; c.pipeline = g0.pipeline;
         c.groupsOpt = g0.groupsOpt; c.fuse = g0.fuse; c.pathMode = g0.pathMode; c.chunkPaths = g0.chunkPaths;
         c.countVisits = g0.countVisits; c.profiling = g0.profiling; c.inlineLeafRoots = g0.inlineLeafRoots; c.cull = g0.cull;
-        c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap;
+        c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap; c.groupInstances = g0.groupInstances;
         c.sortRays = g0.sortRays;
     }
     for (int d = 0; d < n; ++d) {

@@ -58,7 +58,8 @@ struct alignas(16) DInst {        // 224 B
     float inv[16];                // InverseMat4x4(object->world), math.cl:56-183 evaluated once on the host
     float fwd[16];                // object->world
     uint32_t SBTOffset, instanceID, customInstanceID, blasRoot;   // blasRoot: absolute DNode index (reference-order kernel)
-    uint32_t rootDesc0, rootDesc1, _p0, _p1;                      // root of the wide layout, encoded like a DWide child
+    uint32_t rootDesc0, rootDesc1, _p0, _p1;                      // root of the wide layout, encoded like a DWide child (its cone = the whole BLAS's); _p0 = first
+                                                                  // triangle slot of the BLAS
     float rootMin[4];             // root box (tested on entry iff the root is an inner node)
     float rootMax[4];
     // world-space AABB of the root box for the conservative instance pre-test (traverse_coop.h):
@@ -71,7 +72,27 @@ struct alignas(16) DInst {        // 224 B
 // children, so a single 64-byte fetch decides both subtrees and leaf children need no node fetch at
 // all.  Child descriptor (d0, d1): inner child -> d0 = DWide index, d1 = 0;
 //                                  leaf child  -> d0 = first triangle slot, d1 = WIDE_LEAF | count.
-enum : uint32_t { WIDE_LEAF = 0x80000000u };
+// Child descriptor in full:
+//   d1 = bit 31 leaf | bits 24-30 c7 | byte 2 cone y | byte 1 cone x | byte 0 cone z      c7 = triangle count (leaf) or cone T (inner)
+//   d0 = leaf: cone T << 25 | first triangle slot (25 bits);   inner: DWide index
+// The NORMAL CONE of a child (rdx_runtime.cpp derive_accel, kernels.hip "culled walk") bounds how close to parallel a ray can
+// be to any triangle of the leaf / below the inner child: axis byte b = round(127.5 + 127 a), read with v_cvt_f32_ubyte0/1/2;
+// threshold T (7 bits): the culled walk may skip the child only for rays with |d . (b - 127.5)| >= T |d|; T = 127: never.
+enum : uint32_t { WIDE_LEAF = 0x80000000u, WIDE_MAX_LEAF_TRIS = 127u, WIDE_SLOT_BITS = 25u, WIDE_SLOT_MASK = (1u << 25) - 1u, WIDE_CONE_NEVER = 127u };
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define RDX_HD __host__ __device__
+#else
+#define RDX_HD
+#endif
+RDX_HD inline uint32_t wide_count(uint32_t d1) { return (d1 >> 24) & 0x7fu; }              // leaf children
+RDX_HD inline uint32_t wide_slot(uint32_t d0) { return d0 & WIDE_SLOT_MASK; }              // leaf children
+// cone = x | y << 8 | z << 16 | T << 24 (NormalCone::pack)
+RDX_HD inline void wide_desc(bool leaf, uint32_t ref, uint32_t count, uint32_t cone, uint32_t& d0, uint32_t& d1)
+{
+    const uint32_t x = cone & 0xffu, y = (cone >> 8) & 0xffu, z = (cone >> 16) & 0xffu, T = (cone >> 24) & 0x7fu;
+    d1 = (leaf ? WIDE_LEAF : 0u) | ((leaf ? count : T) << 24) | (y << 16) | (x << 8) | z;
+    d0 = leaf ? ((T << WIDE_SLOT_BITS) | (ref & WIDE_SLOT_MASK)) : ref;
+}
 struct alignas(16) DWide {        // 64 B
     float lmin[3]; uint32_t ld0;
     float lmax[3]; uint32_t ld1;

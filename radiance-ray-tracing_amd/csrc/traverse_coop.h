@@ -599,7 +599,7 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 else if (rdsc.y & WIDE_LEAF) {
                     // a BLAS that is a single leaf (a quad, a small box): its triangles are queued right here (below,
                     // converged) instead of costing a leaf-item step of their own -- 15 % of all steps on sample1
-                    uint32_t cnt = rdsc.y & 0x7fffffffu, st = rdsc.x;
+                    uint32_t cnt = wide_count(rdsc.y), st = wide_slot(rdsc.x);
                     while (cnt > 8u) { L.stack[sp * 64u] = leaf_item(st, 8u); ++sp; st += 8u; cnt -= 8u; }
                     cntE = cnt; stE = st;
                     COOP_POP();
@@ -622,13 +622,13 @@ __device__ __forceinline__ void traverse_coop(const AccelView& A, const Policy& 
                 const uint32_t ld0 = __float_as_uint(l0.w), ld1 = __float_as_uint(l1.w);
                 const uint32_t rd0 = __float_as_uint(r0.w), rd1 = __float_as_uint(r1.w);
                 if (ld1 & WIDE_LEAF) {
-                    cntL = ld1 & 0x7fffffffu; stL = ld0;
+                    cntL = wide_count(ld1); stL = wide_slot(ld0);
                     while (cntL > 8u) { L.stack[sp * 64u] = leaf_item(stL, 8u); ++sp; stL += 8u; cntL -= 8u; }   // oversized leaf: rare
                 } else if (slab_fast(R, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z))) {
                     nextL = ld0;
                 }
                 if (rd1 & WIDE_LEAF) {
-                    cntR = rd1 & 0x7fffffffu; stR = rd0;
+                    cntR = wide_count(rd1); stR = wide_slot(rd0);
                     while (cntR > 8u) { L.stack[sp * 64u] = leaf_item(stR, 8u); ++sp; stR += 8u; cntR -= 8u; }
                 } else if (slab_fast(R, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z))) {
                     nextR = rd0;

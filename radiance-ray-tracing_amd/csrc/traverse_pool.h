@@ -95,6 +95,9 @@ static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rul
 #ifndef POOL_MAX_ITER
 #define POOL_MAX_ITER (1u << 24)       // iterations of one wave before it gives up (a full 1080p frame needs ~1e5 per wave)
 #endif
+#ifndef POOL_SHADE_MIN
+#define POOL_SHADE_MIN 32              // lanes a shade step waits for (whole-path policies)
+#endif
 #ifndef POOL_IDLE_MIN
 #define POOL_IDLE_MIN 40               // finished / free lanes a hand-over step waits for (at 6 waves / SIMD: 24: +5 %, 32: +1-2 % frame time)
 #endif
@@ -115,8 +118,11 @@ __device__ __forceinline__ void pool_test_step(const AccelView& A, const uint32_
     if (lane < n) {
         float t, b1, b2;
         if (coop_triangle_regs(tq0, tq1, tq2, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), tmin, tmax, t, b1, b2)) {
-            const uint32_t inst = __float_as_uint(ra.w);
-            const uint32_t low = (inst << COOP_INST_SHIFT) | ((e & COOP_SLOT_MASK) - (__float_as_uint(rb.w) & COOP_SLOT_MASK));      // BLAS-local triangle slot
+            // the instance slot comes from the triangle record when its BLAS belongs to one instance of the shared-transform group
+            // (the ray slot then serves several instances at once), else from the ray slot; tq2.w = first triangle slot of the BLAS
+            const uint32_t tinst = __float_as_uint(tq1.w);
+            const uint32_t inst = tinst != 0xffffffffu ? tinst : __float_as_uint(ra.w);
+            const uint32_t low = (inst << COOP_INST_SHIFT) | ((e & COOP_SLOT_MASK) - __float_as_uint(tq2.w));      // BLAS-local triangle slot
             atomicMin(&best[e >> COOP_LANE_SHIFT], ((unsigned long long)__float_as_uint(t) << 32) | low);
         }
     }
@@ -177,7 +183,6 @@ template <int REC, bool INL, bool CULL, class Policy>
 __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
                                               float tmin, float tmax, uint32_t* __restrict__ lds)
 {
-    static_assert(!Policy::kShades, "the pool engine has no shade step");
     const uint32_t lane = __lane_id();
     const uint32_t PCAP = pool_cap(A.topNeed, A.blasNeed), RESERVE = A.blasNeed + 3u;
     uint32_t* tstack = lds + lane;                         // [level * 64]: top-level entries of this lane's ray
@@ -208,6 +213,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     uint32_t markPrev = 0;                                 // queue position the lane waits for: the tests of the instance it left before it
                                                            // enters the next one -- and, once its walk is over, all of its tests (`finishing`)
     bool finishing = false, anyHit = (REC == 2);
+    bool needShade = false;                                // whole-path policies (Policy::kShades): the lane's closest hit waits for a shade step
     typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
 
@@ -215,24 +221,36 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     // LDS (A.topNeed = ceil(instances / 32) words per lane) plus their count in a register, instead of a stack of mask
     // entries -- a quarter to a tenth of the LDS (25 instances: 1 word instead of 9 per lane), which is residency.
     const bool flatTop = A.topFlat != 0u;
-#define instLeft tsp
+    // flat mode: tsp = pending instances (bits 0-9) | of which in the shared-transform group (bits 10-19) | bit 31: the lane's ray
+    // slot holds the group's object-space ray.  Shared-transform group (rdx_runtime.cpp derive_accel): instances whose inverse
+    // matrices are bit-identical have the same object-space ray, so a lane enters ALL of them on one ray slot -- without waiting,
+    // between two of them, for the subtree and the queued tests of the first to drain -- before it turns to the others.
+#define POOL_ILEFT (tsp & 0x3ffu)
+#define POOL_GLEFT ((tsp >> 10) & 0x3ffu)
+#define POOL_SLOTGROUP (1u << 31)
+    const bool grouping = flatTop && A.groupCount != 0u;
     if (flatTop) for (uint32_t w = 0; w < A.topNeed; ++w) tstack[w * 64u] = 0u;
 #define POOL_INSTBITS (TAG_INST | IDX_MASK)            // top-level cursor in flat mode: "take the next instance from the bitmap"
 #define POOL_TPOP() do {                                                                               \
-        if (flatTop) tcur = instLeft ? POOL_INSTBITS : COOP_NONE;                                      \
+        if (flatTop) tcur = POOL_ILEFT ? POOL_INSTBITS : COOP_NONE;                                    \
         else if (tsp == 0) tcur = COOP_NONE; else { --tsp; tcur = tstack[tsp * 64u]; }                 \
     } while (0)
-#define POOL_DROP() do {       /* the ray needs nothing more from the top level (shadow ray answered) */ \
-        tcur = COOP_NONE;                                                                              \
-        if (flatTop && instLeft) { for (uint32_t w_ = 0; w_ < A.topNeed; ++w_) tstack[w_ * 64u] = 0u; }  \
+#define POOL_DROP() do {       /* the ray needs nothing more from the top level (shadow ray answered); items of the group's */ \
+                               /* instances still in the pool are discarded when they are popped, the lane waits for that    */ \
+        if (flatTop && POOL_ILEFT) { for (uint32_t w_ = 0; w_ < A.topNeed; ++w_) tstack[w_ * 64u] = 0u; }  \
         tsp = 0;                                                                                       \
+        tcur = (grouping && pendN[lane] != 0u) ? POOL_INBLAS : COOP_NONE;                               \
     } while (0)
 #define POOL_FILE_INSTANCES(M16, FIRST) do {            /* up to 16 instances FIRST.. (wave-uniform) with lane mask M16 */ \
         if (flatTop) {                                                                                 \
             const uint32_t wi_ = (FIRST) >> 5, sh_ = (FIRST) & 31u;                                    \
             atomicOr(&tstack[wi_ * 64u], (M16) << sh_);                                                \
             if (sh_ > 16u && ((M16) >> (32u - sh_)) != 0u) atomicOr(&tstack[(wi_ + 1u) * 64u], (M16) >> (32u - sh_)); \
-            instLeft += (uint32_t)__popc(M16);                                                         \
+            tsp += (uint32_t)__popc(M16);                                                              \
+            if (grouping) {      /* (A.groupBits holds one word more than the bitmap) */                \
+                const uint32_t gs_ = (uint32_t)(((((unsigned long long)A.groupBits[wi_ + 1u]) << 32) | A.groupBits[wi_]) >> sh_) & 0xffffu; \
+                tsp += (uint32_t)__popc((M16) & gs_) << 10;                                            \
+            }                                                                                          \
         } else { tstack[tsp * 64u] = TAG_INST | ((M16) << COOP_IMASK_SHIFT) | (FIRST); ++tsp; }        \
     } while (0)
 #define POOL_START_RAY(WALK) do {                                                                      \
@@ -256,7 +274,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
 #endif
         // a lane whose instance has left the pool moves on along its top-level stack
         if (tcur == POOL_INBLAS && pendN[lane] == 0u) { POOL_TPOP(); markPrev = qTail; }       // the tests of the instance just left
-        if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; markPrev = qTail; }
+        if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing && !(Policy::kShades && needShade)) { finishing = true; markPrev = qTail; }
         const bool done = finishing && (int32_t)(qHead - markPrev) >= 0;
         const bool isFree = (rayIdx == COOP_NONE);
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
@@ -270,6 +288,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         const int nPool = (int)min(64u, poolTop);
         const bool workAny = (nTop | nInst) != 0 || poolTop != 0u;
         const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
+        const int nShade = Policy::kShades ? __popcll(__ballot(needShade)) : 0;
 #ifdef COOP_STATS
         stState[0] += __popcll(__ballot(tcur == POOL_INBLAS)); stState[1] += nTop; stState[2] += nInst;
         stState[4] += __popcll(__ballot(finishing && !done)); stState[5] += __popcll(doneMask); stState[6] += __popcll(freeMask); stState[7] += 64;
@@ -302,6 +321,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 const int act = pol.finish(rayIdx, B, o, d, ah, st);
                 finishing = false;
                 if (act == COOP_RELEASE) rayIdx = COOP_NONE;
+                else if (Policy::kShades && act == COOP_SHADE) needShade = true;
                 else { anyHit = (REC == 2) || (REC == 3 && ah); POOL_START_RAY(true); }
             }
             if (!exhausted) {
@@ -335,9 +355,24 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             }
             continue;
         }
+        // ---- shade step (whole-path policies): the lanes whose closest-hit ray found something run the hit shader together.
+        // The shader is fat (~1700 vector instructions), so it waits for POOL_SHADE_MIN lanes -- or for the wave to have nothing else.
+        if (Policy::kShades && nShade > 0 && (nShade >= POOL_SHADE_MIN || (!workAny && qTail == qHead && nIdle == 0))) {
+            COOP_STAT(1, nShade);
+            if (needShade) {
+                bool ah = false;
+                const int act = pol.shade(rayIdx, o, d, ah, st);
+                needShade = false;
+                if (act == COOP_RELEASE) rayIdx = COOP_NONE;
+                else { anyHit = (REC == 2) || (REC == 3 && ah); POOL_START_RAY(true); }
+            }
+            continue;
+        }
         if (!workAny) {
             if (qTail != qHead) { POOL_TEST(); continue; }
-            if (__ballot(rayIdx != COOP_NONE) == 0ull) { finished = true; break; }      // exhausted, every lane free, queue and pool empty
+            if (__ballot(rayIdx != COOP_NONE) == 0ull) {
+                finished = true; break;              // exhausted, every lane free, queue and pool empty
+            }
             continue;                                              // lanes still finishing: next round hands them over
         }
         if (qTail - qHead >= POOL_TEST_MIN) { POOL_TEST(); continue; }
@@ -465,15 +500,15 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                                     for (uint32_t k = 0; k < min(16u, count - b0); ++k) {
                                         const uint32_t ci = w.y + b0 + k;              // the same instance for every lane here
                                         const DInst& I = A.insts[ci];
-                                        const uint32_t rcnt = I.rootDesc1 & 0x7fffffffu;
+                                        const uint32_t rcnt = wide_count(I.rootDesc1);
                                         if ((I.rootDesc1 & WIDE_LEAF) && rcnt <= 8u) {
                                             if (!((REC != 1) && anyHit && L.best[lane] != ~0ull)) {
                                                 const f3 ro = mat4_mul3(I.inv, o.x, o.y, o.z, 1.0f);
                                                 const f3 rd = mat4_mul3(I.inv, d.x, d.y, d.z, 0.0f);
                                                 for (uint32_t j = 0; j < rcnt; ++j) {
                                                     float t, b1, b2;
-                                                    if (coop_triangle(A, I.rootDesc0 + j, ro, rd, tmin, tmax, t, b1, b2)) {
-                                                        const uint32_t low = (ci << COOP_INST_SHIFT) | (I.rootDesc0 + j - I._p0);
+                                                    if (coop_triangle(A, wide_slot(I.rootDesc0) + j, ro, rd, tmin, tmax, t, b1, b2)) {
+                                                        const uint32_t low = (ci << COOP_INST_SHIFT) | (wide_slot(I.rootDesc0) + j - I._p0);
                                                         atomicMin(&L.best[lane], ((unsigned long long)__float_as_uint(t) << 32) | low);
                                                     }
                                                 }
@@ -533,47 +568,59 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         // ---- instance entry (radiance.cl:161-169): the BLAS root goes into the pool ----------------------------------
     pool_instance_step:
         if (chainInst || (nInst > 0 && nInst * POOL_W_INST >= nPool * 4 && PCAP - poolTop >= 64u + RESERVE)) {
-            const bool ready = isInst && (int32_t)(qHead - markPrev) >= 0;
+            // a lane with instances of the shared-transform group pending enters one whatever it has in the pool or in the test queue
+            // (same ray slot); any other instance waits for the queued tests of the instance left before (`markPrev`)
+            const bool grpNext = grouping && POOL_GLEFT != 0u;
+            const bool ready = isInst && (grpNext || (int32_t)(qHead - markPrev) >= 0);
             if (__ballot(ready) == 0ull) { POOL_TEST(); continue; }
             COOP_STAT(5, __popcll(__ballot(ready)));
             if (REC != 1) { if (anyHit && ready && L.best[lane] != ~0ull) POOL_DROP(); }
             uint32_t cntE = 0, stE = 0, rootNode = COOP_NONE;
-            if (ready && tcur != COOP_NONE) {
+            if (ready && tcur != COOP_NONE && tcur != POOL_INBLAS) {
                 uint32_t ci = tcur & COOP_IFIRST_MASK;
-                if (flatTop) {       // the lowest pending instance of the bitmap
+                if (flatTop) {       // the lowest pending instance of the bitmap (of the group first)
                     ci = 0;
                     for (uint32_t w_ = 0; w_ < A.topNeed; ++w_) {
                         const uint32_t v_ = tstack[w_ * 64u];
-                        if (v_) { ci = w_ * 32u + (uint32_t)__ffs((int)v_) - 1u; tstack[w_ * 64u] = v_ & (v_ - 1u); break; }
+                        const uint32_t c_ = grpNext ? (v_ & A.groupBits[w_]) : v_;
+                        if (c_) { const uint32_t b_ = (uint32_t)__ffs((int)c_) - 1u; ci = w_ * 32u + b_; tstack[w_ * 64u] = v_ & ~(1u << b_); break; }
                     }
-                    --instLeft;
+                    tsp -= grpNext ? 0x401u : 1u;
                 } else {
                     const uint32_t m16 = (tcur >> COOP_IMASK_SHIFT) & 0xffffu, rest = m16 & (m16 - 1u);
                     ci += (uint32_t)__ffs((int)m16) - 1u;
                     if (rest) { tstack[tsp * 64u] = TAG_INST | (rest << COOP_IMASK_SHIFT) | (tcur & COOP_IFIRST_MASK); ++tsp; }
                 }
                 const float4* ip = reinterpret_cast<const float4*>(A.insts + ci);
-                float m[16];
-                *reinterpret_cast<float4*>(m + 0) = ip[0];
-                *reinterpret_cast<float4*>(m + 4) = ip[1];
-                *reinterpret_cast<float4*>(m + 8) = ip[2];
-                *reinterpret_cast<float4*>(m + 12) = ip[3];
-                // the ray in the instance's space goes into this lane's slot: the queued tests of the instance left before are
-                // done (`ready`)
-                RayInst R;
-                R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
-                R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
-                R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
-                const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
-                const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
-                R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
                 const uint4 rdsc = *reinterpret_cast<const uint4*>(ip + 9);    // rootDesc0, rootDesc1, triBase, -
-                {   // slot words 3 / 7: instance slot; first triangle slot of the instance (25 bits) | flags << 29 (bit 0 exactOnly, bit 2 anyHit)
+                RayInst R;
+                if (grpNext && (tsp & POOL_SLOTGROUP)) {
+                    // the slot already holds the group's ray: no matrix, no transform, no slot write
+                    const float4 ra = POOL_RA(rays, lane), rb = POOL_RB(rays, lane);
+                    R.o = mk3(ra.x, ra.y, ra.z); R.d = mk3(rb.x, rb.y, rb.z);
+                    R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
+                    R.exactOnly = ((__float_as_uint(rb.w) >> 29) & 1u) != 0u;
+                } else {
+                    float m[16];
+                    *reinterpret_cast<float4*>(m + 0) = ip[0];
+                    *reinterpret_cast<float4*>(m + 4) = ip[1];
+                    *reinterpret_cast<float4*>(m + 8) = ip[2];
+                    *reinterpret_cast<float4*>(m + 12) = ip[3];
+                    // the ray in the instance's space goes into this lane's slot: the queued tests of the instance left before are
+                    // done (`ready`)
+                    R.o = mat4_mul3(m, o.x, o.y, o.z, 1.0f);
+                    R.d = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
+                    R.rcp = mk3(__builtin_amdgcn_rcpf(R.d.x), __builtin_amdgcn_rcpf(R.d.y), __builtin_amdgcn_rcpf(R.d.z));
+                    const float amin = fminf(fminf(fabsf(R.d.x), fabsf(R.d.y)), fabsf(R.d.z));
+                    const float amax = fmaxf(fmaxf(fabsf(R.rcp.x), fabsf(R.rcp.y)), fabsf(R.rcp.z));
+                    R.exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
+                    // slot words 3 / 7: instance slot (instances outside the group); flags << 29 (bit 0 exactOnly, bit 2 anyHit)
                     POOL_RA(rays, lane) = make_float4(R.o.x, R.o.y, R.o.z, __uint_as_float(ci));
-                    POOL_RB(rays, lane) = make_float4(R.d.x, R.d.y, R.d.z, __uint_as_float(rdsc.z | (((R.exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)) << 29)));
+                    POOL_RB(rays, lane) = make_float4(R.d.x, R.d.y, R.d.z, __uint_as_float(((R.exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)) << 29));
+                    if (grpNext) tsp |= POOL_SLOTGROUP;
                 }
-                if (rdsc.y & WIDE_LEAF) {
-                    cntE = rdsc.y & 0x7fffffffu; stE = rdsc.x;
+                if (rdsc.y & WIDE_LEAF) {      // (never an instance of the group: derive_accel keeps leaf roots out of it)
+                    cntE = wide_count(rdsc.y); stE = wide_slot(rdsc.x);
                     POOL_TPOP();
                 } else {
                     const float4 rmin = ip[10], rmax = ip[11];
@@ -582,11 +629,26 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                         float tnRoot;
                         enter = slab_fast_t(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z), tnRoot);
                         const uint32_t hb = reinterpret_cast<const uint32_t*>(L.best)[2u * lane + 1u];
-                        if (!anyHit && hb != 0xffffffffu && tnRoot > __uint_as_float(hb) * RDX_CULL_K) enter = false;
-                        if (tnRoot > tmax * RDX_CULL_K) enter = false;
+                        // gate of the whole BLAS: the root descriptor's normal cone, every vertex is inside the root box
+                        const CullGate G = cull_gate(R, cull_ray(R), rdsc.x, rdsc.y, false, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z));
+                        float tlim = tmax;
+                        if (!anyHit && hb != 0xffffffffu) tlim = fminf(tlim, __uint_as_float(hb));
+                        if (tnRoot > cull_limit(G, tlim)) enter = false;
                     } else enter = slab_fast(R, mk3(rmin.x, rmin.y, rmin.z), mk3(rmax.x, rmax.y, rmax.z));
-                    if (enter) { rootNode = rdsc.x; pendN[lane] = 1u; tcur = POOL_INBLAS; }
-                    else POOL_TPOP();
+                    if (enter) rootNode = rdsc.x;
+                    if (!grpNext) {
+                        if (enter) { pendN[lane] = 1u; tcur = POOL_INBLAS; }
+                        else POOL_TPOP();
+                    } else {
+                        // the group's instances are all in the pool together: the count is the sum over them.  The lane asks for the
+                        // next instance step while the group has more, then waits for the pool (top of the loop), then moves on
+                        const uint32_t pn = pendN[lane] + (enter ? 1u : 0u);
+                        if (enter) pendN[lane] = pn;
+                        if (POOL_GLEFT == 0u) {
+                            if (pn != 0u) tcur = POOL_INBLAS;
+                            else { POOL_TPOP(); markPrev = qTail; }      // (the slot serves the group's queued tests until they are done)
+                        }
+                    }
                 }
             }
             {
@@ -638,22 +700,26 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                     const uint32_t ld0 = __float_as_uint(l0.w), ld1 = __float_as_uint(l1.w);
                     const uint32_t rd0 = __float_as_uint(r0.w), rd1 = __float_as_uint(r1.w);
                     if (CULL) {
-                        float cullT = tmax * RDX_CULL_K;
-                        if (((REC == 1) || !(qf & 4u)) && hb != 0xffffffffu) cullT = fminf(cullT, __uint_as_float(hb) * RDX_CULL_K);
-                        float tnL = 0.f, tnR = 0.f;
+                        // each child's gate (kernels.hip "culled walk"): its normal cone against the ray, its box holds its vertices
+                        const CullRay CR = cull_ray(Q);
                         const bool leafL = (ld1 & WIDE_LEAF) != 0u, leafR = (rd1 & WIDE_LEAF) != 0u;
-                        if (cull_child(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), leafL, cullT, tnL)) {
-                            if (leafL) { cntL = ld1 & 0x7fffffffu; stL = ld0; } else pushL = ld0;
+                        const CullGate GL = cull_gate(Q, CR, ld0, ld1, leafL, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z));
+                        const CullGate GR = cull_gate(Q, CR, rd0, rd1, leafR, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z));
+                        float tlim = tmax;
+                        if (((REC == 1) || !(qf & 4u)) && hb != 0xffffffffu) tlim = fminf(tlim, __uint_as_float(hb));
+                        float tnL = 0.f, tnR = 0.f;
+                        if (cull_child(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), leafL, GL, tlim, tnL)) {
+                            if (leafL) { cntL = wide_count(ld1); stL = wide_slot(ld0); } else pushL = ld0;
                         }
-                        if (cull_child(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), leafR, cullT, tnR)) {
-                            if (leafR) { cntR = rd1 & 0x7fffffffu; stR = rd0; } else pushR = rd0;
+                        if (cull_child(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), leafR, GR, tlim, tnR)) {
+                            if (leafR) { cntR = wide_count(rd1); stR = wide_slot(rd0); } else pushR = rd0;
                         }
                         // the nearer child goes on top of the LIFO (the "L" slot is written above the "R" slot below)
                         if (pushL != COOP_NONE && pushR != COOP_NONE && tnL > tnR) { const uint32_t t_ = pushL; pushL = pushR; pushR = t_; }
                     } else {
-                        if (ld1 & WIDE_LEAF) { cntL = ld1 & 0x7fffffffu; stL = ld0; }
+                        if (ld1 & WIDE_LEAF) { cntL = wide_count(ld1); stL = wide_slot(ld0); }
                         else if (slab_fast(Q, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z))) pushL = ld0;
-                        if (rd1 & WIDE_LEAF) { cntR = rd1 & 0x7fffffffu; stR = rd0; }
+                        if (rd1 & WIDE_LEAF) { cntR = wide_count(rd1); stR = wide_slot(rd0); }
                         else if (slab_fast(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z))) pushR = rd0;
                     }
                     delta += (pushL != COOP_NONE ? 1 : 0) + (pushR != COOP_NONE ? 1 : 0);
@@ -692,7 +758,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     pol.retire(st);
 #undef POOL_TEST
 #undef POOL_ENQ
-#undef instLeft
+#undef POOL_ILEFT
+#undef POOL_GLEFT
+#undef POOL_SLOTGROUP
 #undef POOL_TPOP
 #undef POOL_DROP
 #undef POOL_FILE_INSTANCES

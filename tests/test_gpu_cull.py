@@ -46,7 +46,7 @@ def ref(gpu):
 
 def _bits(a):
     a = np.ascontiguousarray(a)
-    return a.view(np.uint8).reshape(a.shape[0], -1)
+    return a.view(np.uint8).reshape(a.shape[0], -1) if a.shape[0] else np.zeros((0, 1), np.uint8)
 
 
 def _mismatches(want, got, closest):

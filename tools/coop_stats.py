@@ -14,7 +14,10 @@ fn = L.rdx_debug_coop_stats
 fn.restype = ctypes.c_int
 if os.environ.get("RDX_CULL"):
     rd.SetOption("cull", int(os.environ["RDX_CULL"]))
-for cfg, w, h in (("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_cornell", 680, 381)):
+CFGS = [("c1_cornell", 1920, 1080), ("c2_atrium", 1920, 1080), ("c1_cornell", 680, 381)]
+if os.environ.get("RDX_STATS_CFG"):          # e.g. RDX_STATS_CFG=c2_atrium,c4_atrium_10m
+    CFGS = [(c, 1920, 1080) for c in os.environ["RDX_STATS_CFG"].split(",")]
+for cfg, w, h in CFGS:
     s = scenes.CONFIGS[cfg](w, h, 4, 8)
     dev = scenes.DeviceScene(s)
     dev.render()
