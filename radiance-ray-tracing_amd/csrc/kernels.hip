@@ -1078,26 +1078,106 @@ __device__ __attribute__((noinline)) void shade_call(const AccelView* A, const S
     *out = p;
 }
 
+// A wave owns its paths (traverse_pool.h "whole-path policies").  Work item = camera ray index (= path id) or a path id from
+// the wave's ray queue | POOL_QUEUED: first the shadow query the closest-hit shader asked for, then the next bounce's ray.
+// Path state lives in the path streams, indexed by path id and touched by the owning wave only:
+//   rayO = current ray origin | pixel      rayD = direction | frameID      thr = contribution | owned-pixel slot
+//   col = colour so far | depth            hitA = t, b1, b2, triangle slot  hitInst = instance slot
+//   shO = shadow origin | query wanted     colLit = colour if lit | depth   colSh = colour if occluded
+// Arithmetic per value is that of the staged kernels (k_generate / k_shade / ShadowPolicy): frames are bit-identical.
 struct PathPolicy {
     AccelView A; SceneArgs sc; CameraArgs C; PathStreams ps; const uint32_t* owned;
     uint32_t nPixels, sampleBegin, totalSamples, maxDepth, sampleBase;
     f3 Ldir;
-    unsigned long long* tally;        // [0] closest-hit rays, [1] shadow rays (= closest hits)
-    struct State { uint32_t pixel, frameID, depth, triSlot, inst; float t, b1, b2;
-                   uint32_t nClosest, nShadow; };      // rays started by this lane (never reset by load): summed in retire()
+    unsigned long long* tally;        // [0] closest-hit rays, [1] shadow rays
+    struct State { uint32_t phase;    // 0 closest-hit ray, 1 shadow query, 2 nothing to trace (the path ended in load)
+                   uint32_t nClosest, nShadow; };      // rays started by this lane (never reset): summed in retire()
     static constexpr bool kShades = true;
 
-    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit, State& st) const
+    __device__ __forceinline__ void end_path(uint32_t p, f3 c) const
     {
-        const uint32_t sLocal = i / nPixels, slot = i - sLocal * nPixels;
-        st.pixel = owned ? owned[slot] : slot;
-        st.frameID = totalSamples + sampleBegin + sLocal;
-        st.depth = 0;
-        camera_ray(C, st.pixel, pcg3d(st.frameID, totalSamples, st.pixel), o, d);     // shader.cl:205
-        ps.thr[i] = make_float4(1.0f, 1.0f, 1.0f, u2f(slot));
-        ps.col[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        anyHit = false;
-        st.nClosest++;
+        store_sample(ps, nPixels, sampleBase, f2u(ps.rayD[p].w), f2u(ps.thr[p].w), c);
+    }
+    // colour after bounce `depth` is `c`: the path ends, or its next ray (written by the shade step) starts
+    __device__ __forceinline__ bool advance(uint32_t p, f3 c, uint32_t depth, f3& o, f3& d, bool& anyHit, State& st) const
+    {
+        if (depth + 1 >= maxDepth) { end_path(p, c); st.phase = 2; return false; }
+        ps.col[p] = make_float4(c.x, c.y, c.z, u2f(depth + 1));
+        const float4 ro = ps.rayO[p], rd = ps.rayD[p];
+        o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z); anyHit = false;
+        st.phase = 0; st.nClosest++;
+        return true;
+    }
+    __device__ __forceinline__ bool load(uint32_t idx, f3& o, f3& d, bool& anyHit, State& st) const
+    {
+        if (!(idx & POOL_QUEUED)) {          // camera ray of path idx (shader.cl:196-231)
+            const uint32_t p = idx, sLocal = p / nPixels, slot = p - sLocal * nPixels;
+            const uint32_t pixel = owned ? owned[slot] : slot, frameID = totalSamples + sampleBegin + sLocal;
+            camera_ray(C, pixel, pcg3d(frameID, totalSamples, pixel), o, d);     // shader.cl:205
+            ps.rayO[p] = make_float4(o.x, o.y, o.z, u2f(pixel));
+            ps.rayD[p] = make_float4(d.x, d.y, d.z, u2f(frameID));
+            ps.thr[p] = make_float4(1.0f, 1.0f, 1.0f, u2f(slot));
+            ps.col[p] = make_float4(0.0f, 0.0f, 0.0f, u2f(0u));
+            anyHit = false; st.phase = 0; st.nClosest++;
+            return true;
+        }
+        const uint32_t p = idx & ~POOL_QUEUED;
+        const float4 so = ps.shO[p];
+        if (so.w != 0.0f) {                  // traceRay(topLevel, 2, 4, hitPos, L, ...) (shader.cl:499-501)
+            o = mk3(so.x, so.y, so.z); d = Ldir; anyHit = true;
+            st.phase = 1; st.nShadow++;
+            return true;
+        }
+        const float4 cl = ps.colLit[p];      // no shadow query: the colour is the lit one
+        return advance(p, mk3(cl.x, cl.y, cl.z), f2u(cl.w), o, d, anyHit, st);
+    }
+    __device__ __forceinline__ int finish(uint32_t idx, const Best& b, f3& o, f3& d, bool& anyHit, State& st) const
+    {
+        const uint32_t p = idx & ~POOL_QUEUED;
+        if (st.phase == 1) {
+            // the shadow query is answered: hit -> closest-hit row 2 `shadow`, miss -> row 4 `shadowMiss`
+            Payload sp; sp.hit = false;
+            if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit(2, sp, hh, sv, Ldir, 0, 0, 0, false); }      // SBTOffset is 0 on this engine, see ShadowPolicy
+            else callMiss(4, sp);
+            const float4 cl = ps.colLit[p];
+            const float4 c = sp.hit ? ps.colSh[p] : cl;
+            return advance(p, mk3(c.x, c.y, c.z), f2u(cl.w), o, d, anyHit, st) ? COOP_NEWRAY : COOP_RELEASE;
+        }
+        if (st.phase == 2) return COOP_RELEASE;
+        if (!b.hit) {            // miss shader, row 3; a primary miss shows its colour, a later one ends the path (shader.cl:243-252)
+            Payload pm; pm.hit = false; pm.color = mk3(0.f, 0.f, 0.f); pm.colorOccluded = pm.color;
+            callMiss(3, pm);
+            const float4 c = ps.col[p];
+            end_path(p, f2u(c.w) == 0u ? pm.color : mk3(c.x, c.y, c.z));
+            return COOP_RELEASE;
+        }
+        ps.hitA[p] = make_float4(b.t, b.b1, b.b2, u2f(b.slot));
+        ps.hitInst[p] = b.inst;
+        return COOP_SHADE;       // the engine queues the path for a shade step and frees the lane
+    }
+    // closest-hit shader of path p (any lane of the owning wave); true: the path goes on (ray queue)
+    __device__ __forceinline__ bool shade_path(uint32_t p, State&) const
+    {
+        const float4 ro = ps.rayO[p], rd = ps.rayD[p], thr = ps.thr[p], col = ps.col[p], ha = ps.hitA[p];
+        const uint32_t depth = f2u(col.w);
+        Payload pl;
+        const ShadeCall in{mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ha.x, ha.y, ha.z, f2u(ha.w), ps.hitInst[p], f2u(rd.w), f2u(ro.w), depth,
+                           depth + 1 < maxDepth ? 1u : 0u};
+        shade_call(&A, &sc, &in, &pl);
+        const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
+        if (!pl.hit) {               // no closest-hit shader bound for this row: the raygen loop sees a miss
+            end_path(p, depth == 0 ? pl.color : Cc);
+            return false;
+        }
+        const f3 lit = Cc + T * pl.color;              // color += contribution * payload.color (shader.cl:240)
+        const f3 occ = Cc + T * pl.colorOccluded;
+        const f3 tn = T * pl.nextFactor;               // contribution *= payload.nextFactor    (shader.cl:241)
+        ps.thr[p] = make_float4(tn.x, tn.y, tn.z, thr.w);
+        ps.rayO[p] = make_float4(pl.nextRayOrigin.x, pl.nextRayOrigin.y, pl.nextRayOrigin.z, ro.w);
+        ps.rayD[p] = make_float4(pl.nextRayDirection.x, pl.nextRayDirection.y, pl.nextRayDirection.z, rd.w);
+        ps.shO[p] = make_float4(pl.shadowOrigin.x, pl.shadowOrigin.y, pl.shadowOrigin.z, pl.wantsShadowRay ? 1.0f : 0.0f);
+        ps.colLit[p] = make_float4(lit.x, lit.y, lit.z, u2f(depth));
+        ps.colSh[p] = make_float4(occ.x, occ.y, occ.z, 0.0f);
         return true;
     }
     __device__ __forceinline__ void retire(State& st) const      // one atomic per wave per tally, not one per ray
@@ -1105,66 +1185,6 @@ struct PathPolicy {
         uint32_t a = st.nClosest, b = st.nShadow;
         for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
         if (__lane_id() == 0) { atomicAdd(tally + 0, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
-    }
-    __device__ __forceinline__ void end_path(uint32_t i, const State& st, f3 c) const
-    {
-        store_sample(ps, nPixels, sampleBase, st.frameID, f2u(ps.thr[i].w), c);
-    }
-    // colour after this bounce is `c`: either the path ends or its next ray starts (shader.cl:233-260)
-    __device__ __forceinline__ int advance(uint32_t i, f3 c, f3& o, f3& d, bool& anyHit, State& st) const
-    {
-        if (st.depth + 1 >= maxDepth) { end_path(i, st, c); return COOP_RELEASE; }
-        const float4 tn = ps.nThr[i], no = ps.nRayO[i], nd = ps.nRayD[i];
-        ps.col[i] = make_float4(c.x, c.y, c.z, 0.0f);
-        ps.thr[i] = make_float4(tn.x, tn.y, tn.z, ps.thr[i].w);
-        st.depth++;
-        o = mk3(no.x, no.y, no.z); d = mk3(nd.x, nd.y, nd.z); anyHit = false;
-        st.nClosest++;
-        return COOP_NEWRAY;
-    }
-    __device__ __forceinline__ int finish(uint32_t i, const Best& b, f3& o, f3& d, bool& anyHit, State& st) const
-    {
-        if (!anyHit) {
-            if (!b.hit) {            // miss shader, row 3; a primary miss shows its colour, a later one ends the path
-                Payload p; p.hit = false; p.color = mk3(0.f, 0.f, 0.f); p.colorOccluded = p.color;
-                callMiss(3, p);
-                const float4 c = ps.col[i];
-                end_path(i, st, st.depth == 0 ? p.color : mk3(c.x, c.y, c.z));
-                return COOP_RELEASE;
-            }
-            st.t = b.t; st.b1 = b.b1; st.b2 = b.b2; st.triSlot = b.slot; st.inst = b.inst;
-            return COOP_SHADE;
-        }
-        // the shadow query is answered: hit -> closest-hit row 2 `shadow`, miss -> row 4 `shadowMiss`
-        Payload sp; sp.hit = false;
-        if (b.hit) { HitInfo hh{}; SceneView sv{}; callHit(2, sp, hh, sv, Ldir, 0, 0, 0, false); }      // SBTOffset is 0 on this engine, see ShadowPolicy
-        else callMiss(4, sp);
-        const float4 c = sp.hit ? ps.colSh[i] : ps.colLit[i];
-        return advance(i, mk3(c.x, c.y, c.z), o, d, anyHit, st);
-    }
-    __device__ __forceinline__ int shade(uint32_t i, f3& o, f3& d, bool& anyHit, State& st) const
-    {
-        const float4 thr = ps.thr[i], col = ps.col[i];
-        Payload p;
-        const ShadeCall in{o, d, st.t, st.b1, st.b2, st.triSlot, st.inst, st.frameID, st.pixel, st.depth, st.depth + 1 < maxDepth ? 1u : 0u};
-        shade_call(&A, &sc, &in, &p);
-        const f3 T = mk3(thr.x, thr.y, thr.z), Cc = mk3(col.x, col.y, col.z);
-        if (!p.hit) {                // no closest-hit shader bound for this row: the raygen loop sees a miss
-            end_path(i, st, st.depth == 0 ? p.color : Cc);
-            return COOP_RELEASE;
-        }
-        const f3 lit = Cc + T * p.color;               // color += contribution * payload.color (shader.cl:240)
-        const f3 occ = Cc + T * p.colorOccluded;
-        const f3 tn = T * p.nextFactor;                // contribution *= payload.nextFactor    (shader.cl:241)
-        ps.nThr[i] = make_float4(tn.x, tn.y, tn.z, 0.0f);
-        ps.nRayO[i] = make_float4(p.nextRayOrigin.x, p.nextRayOrigin.y, p.nextRayOrigin.z, 0.0f);
-        ps.nRayD[i] = make_float4(p.nextRayDirection.x, p.nextRayDirection.y, p.nextRayDirection.z, 0.0f);
-        if (!p.wantsShadowRay) return advance(i, lit, o, d, anyHit, st);
-        ps.colLit[i] = make_float4(lit.x, lit.y, lit.z, 0.0f);
-        ps.colSh[i] = make_float4(occ.x, occ.y, occ.z, 0.0f);
-        o = p.shadowOrigin; d = Ldir; anyHit = true;   // traceRay(topLevel, 2, 4, hitPos, L, ...) (shader.cl:499-501)
-        st.nShadow++;
-        return COOP_NEWRAY;
     }
 };
 
@@ -1179,7 +1199,7 @@ k_path_pool(AccelView A, SceneArgs sc, CameraArgs C, PathStreams ps, const uint3
     PathPolicy pol{A, sc, C, ps, owned, nPixels, sampleBegin, totalSamples, maxDepth, sampleBase,
                    normalize3(mk3(-ld[0], -ld[1], -ld[2])), tally};
     traverse_pool<3, INL, CULL>(A, pol, nPixels * sampleCount, counter, tmin, tmax,
-                                s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+                                s_stack + (threadIdx.x >> 6) * (pool_words_per_wave(A.topNeed, A.blasNeed) + POOL_PATH_LDS_WORDS));
 }
 
 struct BatchPolicy {
@@ -1466,7 +1486,7 @@ void launch_path(hipStream_t st, const AccelView& av, const SceneArgs& sc, const
 {
     const uint64_t n = (uint64_t)nPixels * sampleCount;
     if (!n) return;
-    size_t lds; const uint32_t th = coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), lds, 5);      // (the caller checks av.kernel == 3)
+    size_t lds; const uint32_t th = coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed) + POOL_PATH_LDS_WORDS, lds, 5);      // (the caller checks av.kernel == 3)
     RDX_POOL_LAUNCH(k_path_pool, dim3(coop_blocks((uint32_t)n, th, lds, 5)), av, sc, cam, ps, owned, nPixels, sampleBegin, sampleCount,
                     totalSamples, maxDepth, sampleBase, counter, tally, tmin, tmax);
 }

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -21,6 +22,10 @@
 #include <thread>
 #include <vector>
 
+#ifndef RDX_SBT_HEADER
+#define RDX_SBT_HEADER "sbt_generated.h"      // tools/genSBT.py output (the table this library's stage kernels were built for)
+#endif
+#include RDX_SBT_HEADER
 #include "bvh_build.h"
 #include "device_math.h"
 #include "kernels.h"
@@ -59,6 +64,7 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
     uint32_t* groupBits = nullptr;     // pool engine: instance slots of the shared-transform group (bitmap, 9 words on the device), see derive_accel
     uint32_t groupCount = 0;
+    uint32_t unifiedRoot = 0, unifiedNeed = 0;   // pool engine: one tree over top level + instances + BLASes (derive_accel), 0 = not built
     void release()
     {
         if (groupBits) HIP_IGN(hipFree(groupBits));
@@ -153,6 +159,7 @@ struct Context {
     int sortRays = -1;                      // option "sort": per-bounce ray sort: 1 on, 0 off, -1 automatic
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int groupInstances = 1;                 // pool engine: instances with bit-identical inverse matrices share one ray slot (option "group_instances")
+    int unifiedTree = 1;                    // pool engine: large top levels of identity instances are walked by the pool (option "unified_tree")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
     rdx_trace_stats stats{};
@@ -293,6 +300,35 @@ struct NormalCone {
     }
 };
 
+// Can the order-free engines (pool / cooperative / per-lane wide) trace instances whose SBT offset is k?  They assume that a
+// radiance ray's row (1 + k) has NO any-hit shader -- so the winner is the minimum, whatever the visiting order -- and that a
+// shadow ray's row (2 + k) is the stock pair: an any-hit shader that ends the walk at the first accepted candidate and a
+// closest-hit shader that only flags the hit (`anyShadow` / `shadow`: neither looks at WHICH candidate it was).  Rows are those
+// of the sbt.json this library was generated from (tools/genSBT.py -> sbt_generated.h); k = 0 always qualifies for the stock
+// table.  Anything else keeps the reference's DFS order: the reference-order kernel.
+bool sbt_offset_is_order_free(uint32_t k)
+{
+    struct Row { int row; const char* fn; };
+    static const Row anyHit[] = {
+#define X(row, fn) {row, #fn},
+        RDX_SBT_ANY_HIT(X)
+#undef X
+        {-1, nullptr}};
+    static const Row closest[] = {
+#define X(row, fn) {row, #fn},
+        RDX_SBT_CLOSEST_HIT(X)
+#undef X
+        {-1, nullptr}};
+    auto find = [](const Row* t, int row) -> const char* { for (; t->fn; ++t) if (t->row == row) return t->fn; return nullptr; };
+    if (k > 1000000u) return false;
+    const int r1 = 1 + (int)k, r2 = 2 + (int)k;
+    if (find(anyHit, r1)) return false;
+    const char* a2 = find(anyHit, r2); const char* c2 = find(closest, r2);
+    const char* a0 = find(anyHit, 2); const char* c0 = find(closest, 2);
+    auto same = [](const char* x, const char* y) { return (x == nullptr && y == nullptr) || (x && y && !std::strcmp(x, y)); };
+    return same(a2, a0) && same(c2, c0);
+}
+
 int derive_accel(rdx_buffer_s* tb)
 {
     if (acc(tb) && acc(tb)->version == tb->version) return 0;
@@ -352,9 +388,10 @@ int derive_accel(rdx_buffer_s* tb)
         const BlobInst& bi = binst[k];
         // Dispatch index = instanceSBTOffset + sbtRecordOffset (radiance.cl:281, shader.cl:574-605).  With a non-zero offset the
         // any-hit shader of a RADIANCE ray's row may end the walk at the first accepted candidate in the reference's DFS order --
-        // an order only the reference-order kernel keeps -- so such scenes are traced by that kernel (the live loader always
-        // writes 0, tools/sceneBuilder.cpp:302; the production engines assume it).
-        if (bi.SBTOffset != 0) sbtOffsets = true;
+        // an order only the reference-order kernel keeps -- so scenes with such a row are traced by that kernel; offsets whose
+        // rows behave like the stock rows 1 / 2 (sbt_offset_is_order_free) stay on the production engines (the live loader always
+        // writes 0, tools/sceneBuilder.cpp:302).
+        if (bi.SBTOffset != 0 && !sbt_offset_is_order_free(bi.SBTOffset)) sbtOffsets = true;
         auto it = blasAt.find(bi.instanceOffset);
         if (it == blasAt.end()) {
             if ((size_t)bi.instanceOffset + 16 > bsz) return fail("TLAS blob: BLAS offset out of range");
@@ -524,6 +561,91 @@ int derive_accel(rdx_buffer_s* tb)
                 for (uint32_t t = 0; t < bi.nTris; ++t) dTri[bi.triBase + t]._p0 = k;
             }
     }
+    // Unified tree (pool engine; scenes whose top level is too large for the flat step: > 64 nodes or > 256 instances -- a loader
+    // that makes one instance per mesh, tools/sceneBuilder.cpp:287-315).  When EVERY instance has the identity transform and a
+    // BLAS of its own, the object-space ray of all instances is one ray (the group's; it equals the world ray up to the sign
+    // of zeros, which no slab decision depends on: (b - o) / d keeps its value, min / max of +-0 or of equally signed infinities
+    // decide the same) -- so top-level nodes can be walked like BLAS nodes, by the pool, on that one ray slot:
+    //   top-level inner node -> wide record (boxes of its two children; an inner child is entered iff its box is hit, as the
+    //                           reference does when it pops the child; a leaf child is always entered: the reference never tests it)
+    //   top-level leaf       -> a balanced fan-out of always-entered pseudo nodes over its instances
+    //   instance             -> a child entry whose box is the BLAS root box and whose descriptor is the BLAS root (the root
+    //                           test of radiance.cl:61-63 for an inner root; a leaf root has its triangles tested directly)
+    // One item -- a super-root that holds the top-level root's box -- starts a ray; no top-level step, no instance step.
+    uint32_t unifiedRoot = 0, unifiedNeed = 0;
+    if ((nTop > 64 || nInst > 256) && nInst >= 2 && !(tnodes[0].w0 & LEAF_BIT) && !sbtOffsets) {
+        bool ok = true;
+        for (uint32_t k = 0; k < nInst && ok; ++k) {
+            const BlasInfo& bi = blasAt[binst[k].instanceOffset];
+            if (bi.users != 1) ok = false;
+            for (int e = 0; e < 16 && ok; ++e) if (!(dI[k].inv[e] == ((e % 5 == 0) ? 1.0f : 0.0f))) ok = false;      // (zero signs do not matter)
+            if (std::memcmp(dI[k].inv, dI[0].inv, 64) != 0) ok = false;                                               // ... but one ray needs one matrix
+        }
+        if (ok) {
+            const float BIG = 1.0e30f;
+            const uint32_t never = WIDE_CONE_NEVER << 24;
+            auto always = [&](float* mn, float* mx) { for (int k = 0; k < 3; ++k) { mn[k] = -BIG; mx[k] = BIG; } };
+            auto none = [&](float* mn, float* mx, uint32_t& d0, uint32_t& d1) { for (int k = 0; k < 3; ++k) { mn[k] = 0.f; mx[k] = 0.f; } wide_desc(true, 0u, 0u, never, d0, d1); };
+            auto inst_child = [&](uint32_t k, float* mn, float* mx, uint32_t& d0, uint32_t& d1) {
+                for (int c = 0; c < 3; ++c) { mn[c] = dI[k].rootMin[c]; mx[c] = dI[k].rootMax[c]; }
+                d0 = dI[k].rootDesc0; d1 = dI[k].rootDesc1;
+                const BlasInfo& bi = blasAt[binst[k].instanceOffset];
+                for (uint32_t t = 0; t < bi.nTris; ++t) dTri[bi.triBase + t]._p0 = k;          // the candidate's instance comes from the triangle
+            };
+            // fan-out over instances [a, b): returns the child entry for that range
+            std::function<uint32_t(uint32_t, uint32_t, float*, float*, uint32_t&, uint32_t&)> range_child =
+                [&](uint32_t a, uint32_t b, float* mn, float* mx, uint32_t& d0, uint32_t& d1) -> uint32_t {
+                    if (b - a == 1) { inst_child(a, mn, mx, d0, d1); return (dI[a].rootDesc1 & WIDE_LEAF) ? 0u : 1u + blasAt[binst[a].instanceOffset].anyNeed; }
+                    const uint32_t mid = a + (b - a) / 2;
+                    const uint32_t idx = (uint32_t)dW.size();
+                    dW.emplace_back();
+                    DWide w{};
+                    const uint32_t hl = range_child(a, mid, w.lmin, w.lmax, w.ld0, w.ld1);
+                    const uint32_t hr = range_child(mid, b, w.rmin, w.rmax, w.rd0, w.rd1);
+                    dW[idx] = w;
+                    always(mn, mx);
+                    wide_desc(false, idx, 0u, never, d0, d1);
+                    return 1u + std::max(hl, hr);
+                };
+            // top-level nodes, children first (DFS pre-order: children have larger indices)
+            std::vector<uint32_t> uIdx(nTop, 0), uH(nTop, 0);
+            for (uint32_t i = nTop; i-- > 0;) {
+                const BlobNode& n = tnodes[i];
+                if (n.w0 & LEAF_BIT) continue;
+                const uint32_t idx = (uint32_t)dW.size();
+                dW.emplace_back();
+                DWide w{};
+                uint32_t h[2] = {0, 0};
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t ch = c ? n.w1 : n.w0;
+                    float* mn = c ? w.rmin : w.lmin; float* mx = c ? w.rmax : w.lmax;
+                    uint32_t& d0 = c ? w.rd0 : w.ld0; uint32_t& d1 = c ? w.rd1 : w.ld1;
+                    const BlobNode& cn = tnodes[ch];
+                    if (!(cn.w0 & LEAF_BIT)) {
+                        for (int k = 0; k < 3; ++k) { mn[k] = cn.bottom[k]; mx[k] = cn.top[k]; }
+                        wide_desc(false, uIdx[ch], 0u, never, d0, d1);
+                        h[c] = 1u + uH[ch];
+                    } else {
+                        const uint32_t cnt = cn.w2 == TYPE_INST ? (cn.w0 & 0x7fffffffu) : 0u;
+                        if (cnt == 0) none(mn, mx, d0, d1);
+                        else {
+                            h[c] = range_child(cn.w1, cn.w1 + cnt, mn, mx, d0, d1);      // (one instance: its root test is this child's box test)
+                        }
+                    }
+                }
+                dW[idx] = w;
+                uIdx[i] = idx; uH[i] = std::max(h[0], h[1]);
+            }
+            // super-root: the reference tests the top-level root's own box when it pops it
+            DWide sr{};
+            for (int k = 0; k < 3; ++k) { sr.lmin[k] = tnodes[0].bottom[k]; sr.lmax[k] = tnodes[0].top[k]; }
+            wide_desc(false, uIdx[0], 0u, never, sr.ld0, sr.ld1);
+            none(sr.rmin, sr.rmax, sr.rd0, sr.rd1);
+            unifiedRoot = (uint32_t)dW.size();
+            dW.push_back(sr);
+            unifiedNeed = uH[0] + 2u;
+        }
+    }
     // stack need: TLAS part
     // (cooperative kernel: the instances of a top-level leaf are pushed as 16-bit masks, one entry per 16 instances,
     //  and the entry being consumed is pushed back while one of its instances is walked)
@@ -579,6 +701,7 @@ int derive_accel(rdx_buffer_s* tb)
     for (int k = 0; k < 3; ++k) { ac->sceneLo[k] = tnodes[0].bottom[k]; ac->sceneHi[k] = tnodes[0].top[k]; }
     ac->sbtOffsets = sbtOffsets || hugeLeaf;      // (either way: the reference-order kernel, which reads the blob's own node layout)
     ac->groupCount = groupCount;
+    ac->unifiedRoot = unifiedRoot; ac->unifiedNeed = unifiedNeed;
     ac->nWide = (uint32_t)dW.size();
     // per-lane kernels: [need][64 lanes] words of LDS per wave, 64 KB at most
     if (ac->stackNeed > 250) return fail("BVH too deep for the LDS traversal stack: %u entries per ray needed, 250 available", ac->stackNeed);
@@ -630,7 +753,14 @@ AccelView view_of(const rdx_buffer_s* tb)
     v.numInsts = acc(tb)->nInst;
     if (v.topFlat) v.topNeed = acc(tb)->topFlatNeed;          // flat top level: words per lane of the pending-instance bitmap
     v.leafRoots = (v.topFlat && g.inlineLeafRoots && acc(tb)->leafRoots) ? 1u : 0u;
-    v.groupCount = (v.topFlat && g.groupInstances) ? acc(tb)->groupCount : 0u;
+    v.unifiedRoot = 0;
+    if (v.kernel == 3 && !v.topFlat && g.unifiedTree && acc(tb)->unifiedRoot) {
+        // unified tree: no top-level state per lane at all (one bitmap word stays allocated: the engine's flat-mode bookkeeping)
+        v.unifiedRoot = acc(tb)->unifiedRoot;
+        v.topFlat = 1u; v.topNeed = 1u; v.leafRoots = 0u;
+        v.blasNeed = acc(tb)->unifiedNeed;
+    }
+    v.groupCount = (v.topFlat && !v.unifiedRoot && g.groupInstances) ? acc(tb)->groupCount : 0u;
     v.groupBits = acc(tb)->groupBits;
     return v;
 }
@@ -939,7 +1069,11 @@ extern "C" int rdx_shutdown(void)
     HIP_IGN(hipSetDevice(g_phys[0]));
     HIP_IGN(hipStreamSynchronize(g.stream));
     for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
-    for (auto& sh : g.shaders) if (sh->program) release_user_shader(sh->program);
+    {   // (modules created from the same text share one compiled program: user_shader.cpp's cache)
+        std::vector<UserProgram*> seen;
+        for (auto& sh : g.shaders)
+            if (sh->program && std::find(seen.begin(), seen.end(), sh->program) == seen.end()) { seen.push_back(sh->program); release_user_shader(sh->program); }
+    }
     g.buffers.clear(); g.blases.clear(); g.shaders.clear();
     release_device_state();
     g = Context{};
@@ -1346,7 +1480,7 @@ extern "C" rdx_shader rdx_shader_module_create(const char* code, uint32_t size, 
         arch = arch.substr(0, arch.find(':'));
         std::string err;
         s->program = compile_user_shader(text, g0.shaderInclude, arch, err);
-        if (!s->program) { fail("%s", err.c_str()); return nullptr; }
+        if (!s->program) { fail_str(err); return nullptr; }
     }
     g.shaders.push_back(std::move(s));
     return g.shaders.back().get();
@@ -1450,6 +1584,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "cull")) { g.cull = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
     if (!strcmp(name, "group_instances")) { g.groupInstances = value != 0; return 0; }
+    if (!strcmp(name, "unified_tree")) { g.unifiedTree = value != 0; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
@@ -1771,7 +1906,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         c.nslots = g0.nslots; c.pipeline = g0.pipeline;
         c.groupsOpt = g0.groupsOpt; c.fuse = g0.fuse; c.pathMode = g0.pathMode; c.chunkPaths = g0.chunkPaths;
         c.countVisits = g0.countVisits; c.profiling = g0.profiling; c.inlineLeafRoots = g0.inlineLeafRoots; c.cull = g0.cull;
-        c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap; c.groupInstances = g0.groupInstances;
+        c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap; c.groupInstances = g0.groupInstances; c.unifiedTree = g0.unifiedTree;
         c.sortRays = g0.sortRays;
     }
     for (int d = 0; d < n; ++d) {

@@ -93,11 +93,18 @@ static_assert(POOL_NODE_MASK + 1u >= RDX_COOP_MAX_WIDE, "the host's fallback rul
 #define POOL_W_INST 12
 #endif
 #ifndef POOL_MAX_ITER
-#define POOL_MAX_ITER (1u << 24)       // iterations of one wave before it gives up (a full 1080p frame needs ~1e5 per wave)
+#define POOL_MAX_ITER (1u << 22)       // iterations of one wave before it gives up (a full 1080p frame needs ~1e5 per wave)
 #endif
-#ifndef POOL_SHADE_MIN
-#define POOL_SHADE_MIN 32              // lanes a shade step waits for (whole-path policies)
-#endif
+// Whole-path policies (Policy::kShades; kernels.hip "whole paths"): a wave OWNS its paths from the camera ray to the end.  A
+// closest hit is written to the path's state and the path id goes into the wave's SHADE queue; the lane is free for another
+// ray at once.  When 64 paths wait there, a shade step runs the closest-hit shader on them -- all lanes busy, whatever the
+// lanes' own rays are doing (it touches path state only) -- and the survivors go into the wave's RAY queue, from which free
+// lanes are refilled before new camera rays are taken.  Two small rings in LDS behind the engine's own words; nothing crosses
+// a wave, so no launch ever waits for another and a frame is one ramp and one drain.
+#define POOL_RQ_CAP 256u               // ray queue (entries: path ids).  Bound: camera rays are taken only while it is empty, so a
+#define POOL_SQ_CAP 128u               // wave owns < 64 + 128 paths; shade queue: a hand-over adds <= 64 to < 64 entries
+#define POOL_PATH_LDS_WORDS (POOL_RQ_CAP + POOL_SQ_CAP)
+#define POOL_QUEUED 0x80000000u        // work item = path id | POOL_QUEUED: a path from the ray queue (not a camera ray)
 #ifndef POOL_IDLE_MIN
 #define POOL_IDLE_MIN 40               // finished / free lanes a hand-over step waits for (at 6 waves / SIMD: 24: +5 %, 32: +1-2 % frame time)
 #endif
@@ -195,6 +202,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     L.best = reinterpret_cast<unsigned long long*>(L.ray + POOL_RAY_LDS_WORDS);
     L.pend = nullptr;
     float4* rays = reinterpret_cast<float4*>(L.ray);       // [lane * 2 + parity][2]
+    uint32_t* rayQ = reinterpret_cast<uint32_t*>(L.best + 64);      // whole-path policies only (the kernel allocates POOL_PATH_LDS_WORDS more)
+    uint32_t* shadeQ = rayQ + POOL_RQ_CAP;
+    uint32_t rqHead = 0, rqTail = 0, sqHead = 0, sqTail = 0;        // wave-uniform
 #define POOL_TEST() pool_test_step(A, L.queue, rays, L.best, lane, qHead, qTail, tmin, tmax)
 #define POOL_ENQ(TAG, CNT, START) pool_enqueue(A, L.queue, rays, L.best, lane, TAG, CNT, START, qHead, qTail, tmin, tmax)
     pendN[lane] = 0u;
@@ -213,7 +223,6 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
     uint32_t markPrev = 0;                                 // queue position the lane waits for: the tests of the instance it left before it
                                                            // enters the next one -- and, once its walk is over, all of its tests (`finishing`)
     bool finishing = false, anyHit = (REC == 2);
-    bool needShade = false;                                // whole-path policies (Policy::kShades): the lane's closest hit waits for a shade step
     typename Policy::State st{};
     f3 o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 1.f);
 
@@ -274,7 +283,7 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
 #endif
         // a lane whose instance has left the pool moves on along its top-level stack
         if (tcur == POOL_INBLAS && pendN[lane] == 0u) { POOL_TPOP(); markPrev = qTail; }       // the tests of the instance just left
-        if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing && !(Policy::kShades && needShade)) { finishing = true; markPrev = qTail; }
+        if (rayIdx != COOP_NONE && tcur == COOP_NONE && !finishing) { finishing = true; markPrev = qTail; }
         const bool done = finishing && (int32_t)(qHead - markPrev) >= 0;
         const bool isFree = (rayIdx == COOP_NONE);
         const unsigned long long doneMask = __ballot(done), freeMask = __ballot(isFree);
@@ -287,18 +296,36 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         bool chainInst = false;          // the top-level step hands its rays straight to an instance step (below)
         const int nPool = (int)min(64u, poolTop);
         const bool workAny = (nTop | nInst) != 0 || poolTop != 0u;
-        const int nIdle = __popcll(doneMask) + (exhausted ? 0 : __popcll(freeMask));
-        const int nShade = Policy::kShades ? __popcll(__ballot(needShade)) : 0;
+        // whole-path policies: free lanes can also be refilled from the wave's own ray queue
+        const uint32_t rqN = Policy::kShades ? rqTail - rqHead : 0u, sqN = Policy::kShades ? sqTail - sqHead : 0u;
+        const int nIdle = __popcll(doneMask) + ((exhausted && rqN == 0u) ? 0 : __popcll(freeMask));
 #ifdef COOP_STATS
         stState[0] += __popcll(__ballot(tcur == POOL_INBLAS)); stState[1] += nTop; stState[2] += nInst;
         stState[4] += __popcll(__ballot(finishing && !done)); stState[5] += __popcll(doneMask); stState[6] += __popcll(freeMask); stState[7] += 64;
 #endif
 
+        if (Policy::kShades && (rqN > POOL_RQ_CAP || sqN > POOL_SQ_CAP)) break;       // (cannot happen: see the bounds above; reported like the iteration bound)
+        // ---- shade step (whole-path policies): 64 queued closest hits, or what there is when the wave has nothing else -----
+        if constexpr (Policy::kShades) if (sqN != 0u && (sqN >= 64u || (!workAny && qTail == qHead && nIdle == 0))) {
+            const uint32_t ns = min(64u, sqN);
+            COOP_STAT(1, ns);
+            bool cont = false;
+            uint32_t sp = 0;
+            if (lane < ns) { sp = shadeQ[(sqHead + lane) & (POOL_SQ_CAP - 1u)]; cont = pol.shade_path(sp, st); }
+            sqHead += ns;
+            const unsigned long long cm = __ballot(cont);
+            if (cont) rayQ[(rqTail + lanes_below(cm)) & (POOL_RQ_CAP - 1u)] = sp;
+            rqTail += (uint32_t)__popcll(cm);
+            continue;
+        }
         // ---- hand-over: finished rays are written out, free lanes take new rays -----------------------------------
         // (the pool usually holds 64+ items, so -- unlike traverse_coop.h -- the trigger is an absolute number of idle lanes)
         if (nIdle > 0 && (nIdle >= POOL_IDLE_MIN || !workAny)) {
             COOP_STAT(0, nIdle);
+            bool pushS = false;
+            uint32_t pushP = 0;
             if (done) {
+                pushP = rayIdx & ~POOL_QUEUED;
                 Best B;
                 B.t = FLT_MAX; B.b1 = 0.f; B.b2 = 0.f; B.slot = 0; B.inst = RDX_MISS; B.hit = false;
                 const unsigned long long key = L.best[lane];
@@ -321,10 +348,33 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                 const int act = pol.finish(rayIdx, B, o, d, ah, st);
                 finishing = false;
                 if (act == COOP_RELEASE) rayIdx = COOP_NONE;
-                else if (Policy::kShades && act == COOP_SHADE) needShade = true;
+                else if (Policy::kShades && act == COOP_SHADE) { pushS = true; rayIdx = COOP_NONE; }       // the path goes to the wave's shade queue, the lane is free
                 else { anyHit = (REC == 2) || (REC == 3 && ah); POOL_START_RAY(true); }
             }
-            if (!exhausted) {
+            uint32_t fromQueue = 0;
+            if constexpr (Policy::kShades) {
+                {   // closest hits of this hand-over go to the shade queue (< 64 entries before: the shade step above comes first)
+                    const unsigned long long sm = __ballot(pushS);
+                    if (pushS) shadeQ[(sqTail + lanes_below(sm)) & (POOL_SQ_CAP - 1u)] = pushP;
+                    sqTail += (uint32_t)__popcll(sm);
+                }
+                // free lanes are refilled from the wave's ray queue first
+                const bool want = (rayIdx == COOP_NONE);
+                const unsigned long long wm = __ballot(want);
+                fromQueue = min((uint32_t)__popcll(wm), rqTail - rqHead);
+                const uint32_t rank = lanes_below(wm);
+                if (want && rank < fromQueue) {
+                    const uint32_t idx = rayQ[(rqHead + rank) & (POOL_RQ_CAP - 1u)] | POOL_QUEUED;
+                    rayIdx = idx;
+                    bool ah = false;
+                    const bool walk = pol.load(idx, o, d, ah, st);
+                    anyHit = (REC == 2) || (REC == 3 && ah);
+                    POOL_START_RAY(walk);
+                }
+                rqHead += fromQueue;
+            }
+            // ... and with new work items (camera rays for whole paths: only while the ray queue is empty, which bounds the paths a wave owns)
+            if (!exhausted && (!Policy::kShades || rqHead == rqTail)) {
                 const bool want = (rayIdx == COOP_NONE);
                 const unsigned long long wm = __ballot(want);
                 uint32_t cnt = (uint32_t)__popcll(wm);
@@ -355,22 +405,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
             }
             continue;
         }
-        // ---- shade step (whole-path policies): the lanes whose closest-hit ray found something run the hit shader together.
-        // The shader is fat (~1700 vector instructions), so it waits for POOL_SHADE_MIN lanes -- or for the wave to have nothing else.
-        if (Policy::kShades && nShade > 0 && (nShade >= POOL_SHADE_MIN || (!workAny && qTail == qHead && nIdle == 0))) {
-            COOP_STAT(1, nShade);
-            if (needShade) {
-                bool ah = false;
-                const int act = pol.shade(rayIdx, o, d, ah, st);
-                needShade = false;
-                if (act == COOP_RELEASE) rayIdx = COOP_NONE;
-                else { anyHit = (REC == 2) || (REC == 3 && ah); POOL_START_RAY(true); }
-            }
-            continue;
-        }
         if (!workAny) {
             if (qTail != qHead) { POOL_TEST(); continue; }
-            if (__ballot(rayIdx != COOP_NONE) == 0ull) {
+            if (__ballot(rayIdx != COOP_NONE) == 0ull && rqN == 0u && sqN == 0u) {
                 finished = true; break;              // exhausted, every lane free, queue and pool empty
             }
             continue;                                              // lanes still finishing: next round hands them over
@@ -378,9 +415,36 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         if (qTail - qHead >= POOL_TEST_MIN) { POOL_TEST(); continue; }
 
         // ---- top-level node (radiance.cl:110-150) --------------------------------------------------------------------
-        if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST) {
+        if (nTop > 0 && nTop * POOL_W_TOP >= nPool * 4 && nTop * POOL_W_TOP >= nInst * POOL_W_INST &&
+            (A.unifiedRoot == 0u || PCAP - poolTop >= 64u + RESERVE)) {
             COOP_STAT(4, nTop);
             if (REC != 1) { if (anyHit && isTop && L.best[lane] != ~0ull) POOL_DROP(); }
+            if (A.unifiedRoot != 0u) {
+                // Unified tree (rdx_runtime.cpp derive_accel): top level, instances and BLASes are ONE tree of wide records on ONE
+                // object-space ray -- every instance has the identity transform.  The ray is taken through the (identity) inverse
+                // with the reference's expressions, goes into the lane's slot, and one item -- the super-root -- enters the pool.
+                bool push = false;
+                if (isTop && tcur != COOP_NONE) {
+                    const float4* ip = reinterpret_cast<const float4*>(A.insts);          // (the same matrix for every instance)
+                    float m[16];
+                    *reinterpret_cast<float4*>(m + 0) = ip[0];
+                    *reinterpret_cast<float4*>(m + 4) = ip[1];
+                    *reinterpret_cast<float4*>(m + 8) = ip[2];
+                    *reinterpret_cast<float4*>(m + 12) = ip[3];
+                    const f3 ro = mat4_mul3(m, o.x, o.y, o.z, 1.0f), rdv = mat4_mul3(m, d.x, d.y, d.z, 0.0f);
+                    const f3 rc = mk3(__builtin_amdgcn_rcpf(rdv.x), __builtin_amdgcn_rcpf(rdv.y), __builtin_amdgcn_rcpf(rdv.z));
+                    const float amin = fminf(fminf(fabsf(rdv.x), fabsf(rdv.y)), fabsf(rdv.z));
+                    const float amax = fmaxf(fmaxf(fabsf(rc.x), fabsf(rc.y)), fabsf(rc.z));
+                    const bool exactOnly = !(amin > 1e-20f) || !(amax < 1e20f);
+                    POOL_RA(rays, lane) = make_float4(ro.x, ro.y, ro.z, __uint_as_float(0u));
+                    POOL_RB(rays, lane) = make_float4(rdv.x, rdv.y, rdv.z, __uint_as_float(((exactOnly ? 1u : 0u) | (anyHit ? 4u : 0u)) << 29));
+                    pendN[lane] = 1u; tcur = POOL_INBLAS; push = true;
+                }
+                const unsigned long long pm = __ballot(push);
+                if (push) pool[poolTop + lanes_below(pm)] = (lane << POOL_LANE_SHIFT) | (A.unifiedRoot & POOL_NODE_MASK);
+                poolTop += (uint32_t)__popcll(pm);
+                continue;
+            }
             if (!INL && A.topFlat != 0u) {
                 // Small top-level tree (<= 64 nodes): no walk.  Every node is looked at once, in index order (parents come
                 // before their children, DFS pre-order), by all lanes of the step together.  `reach` says which nodes the

@@ -15,11 +15,22 @@
 // and holds the __kernel entry point that passes null for them; the two units are joined with llvm-link.  User programs
 // therefore cannot sample textures yet (the live reference shader does not either, shader.cl:379-445).
 // `#include "radiance.cl"` etc. resolve through the include path given to rdx_shader_include_path (the reference bakes
-// SHADER_LIB_PATH into its binary, radiance.h:7): the user's copy of the reference's shader library.
+// SHADER_LIB_PATH into its binary, radiance.h:7) and then through the library's OWN device library,
+// radiance-ray-tracing_amd/shader/{radiance,data,math,pbr}.cl next to librdx.so: own text with the reference library's
+// interface, so a program that traces rays needs nothing from the reference's tree.
+//
+// Floating-point contract: user programs are compiled like the stock pipeline computes -- `-ffp-contract=off
+// -cl-fp32-correctly-rounded-divide-sqrt` (contract p of DESIGN.md section 2), ONE contract behind the API.  RDX_JIT_FLAGS
+// replaces those two flags (e.g. RDX_JIT_FLAGS="" for clang's OpenCL defaults, what clBuildProgram("-g -I...") would use).
+//
+// Compiled programs are cached: in the process by a hash of (text, flags, architecture, include path, the device library's
+// files), and on disk (RDX_JIT_CACHE, default /tmp/rdx_jit_cache_<uid>) when no user include path is involved.
 #include "user_shader.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <ftw.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -29,6 +40,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <vector>
 
@@ -86,6 +99,51 @@ int run(const std::vector<std::string>& argv, const std::string& log)
     return (WIFEXITED(status) && WEXITSTATUS(status) == 0) ? 0 : -1;
 }
 
+int rm_entry(const char* path, const struct stat*, int, struct FTW*) { return remove(path); }
+void remove_tree(const std::string& dir) { (void)nftw(dir.c_str(), rm_entry, 16, FTW_DEPTH | FTW_PHYS); }
+
+uint64_t fnv1a(const std::string& t, uint64_t h = 1469598103934665603ull)
+{
+    for (unsigned char c : t) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+// directory of the library's own device library: <directory of librdx.so>/shader
+std::string own_shader_dir()
+{
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&own_shader_dir), &info) || !info.dli_fname) return std::string();
+    std::string so = info.dli_fname;
+    const size_t cut = so.find_last_of('/');
+    return (cut == std::string::npos ? std::string(".") : so.substr(0, cut)) + "/shader";
+}
+
+bool copy_file(const std::string& from, const std::string& to)
+{
+    std::ifstream in(from, std::ios::binary);
+    if (!in) return false;
+    const std::string tmp = to + ".tmp" + std::to_string((long)getpid());
+    { std::ofstream out(tmp, std::ios::binary); if (!out) return false; out << in.rdbuf(); if (!out) return false; }
+    return rename(tmp.c_str(), to.c_str()) == 0;
+}
+
+std::mutex g_cacheLock;
+std::map<uint64_t, UserProgram*> g_cache;          // programs compiled by this process, by key (never unloaded before shutdown)
+
+UserProgram* load_code_object(const std::string& co, std::string& err)
+{
+    auto* p = new UserProgram();
+    hipError_t e = hipModuleLoad(&p->module, co.c_str());
+    if (e == hipSuccess) e = hipModuleGetFunction(&p->entry, p->module, "rdx_user_entry");
+    if (e != hipSuccess) {
+        err = std::string("user shader: loading the compiled program failed: ") + hipGetErrorString(e);
+        if (p->module) (void)hipModuleUnload(p->module);
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
 } // namespace
 
 UserProgram* compile_user_shader(const std::string& text, const std::string& includePath, const std::string& arch, std::string& err)
@@ -95,6 +153,35 @@ UserProgram* compile_user_shader(const std::string& text, const std::string& inc
     const std::string link = clang.substr(0, clang.find_last_of('/') + 1) + "llvm-link";
     const char* envRocm = std::getenv("ROCM_PATH");
     const std::string rocm = envRocm ? envRocm : "/opt/rocm";
+    const char* envFlags = std::getenv("RDX_JIT_FLAGS");
+    const std::string fpFlags = envFlags ? envFlags : "-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt";
+    const std::string ownDir = own_shader_dir();
+
+    // cache key: everything the code object depends on
+    uint64_t key = fnv1a(text);
+    key = fnv1a("|" + fpFlags + "|" + arch + "|" + includePath + "|" + clang, key);
+    for (const char* f : {"radiance.cl", "data.cl", "math.cl", "pbr.cl"}) key = fnv1a(slurp(ownDir + "/" + f), key);
+    {
+        std::lock_guard<std::mutex> lk(g_cacheLock);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) return it->second;
+    }
+    char keyHex[32];
+    std::snprintf(keyHex, sizeof keyHex, "%016llx", (unsigned long long)key);
+    const char* envCache = std::getenv("RDX_JIT_CACHE");
+    const std::string cacheDir = envCache ? envCache : "/tmp/rdx_jit_cache_" + std::to_string((long)getuid());
+    const bool diskCache = includePath.empty() && !(envCache && !*envCache);      // (a user include directory can change under us)
+    const std::string cached = cacheDir + "/" + keyHex + ".co";
+    if (diskCache && exists(cached)) {
+        std::string e2;
+        if (UserProgram* p = load_code_object(cached, e2)) {
+            p->log = "(code object from the cache: " + cached + ")";
+            std::lock_guard<std::mutex> lk(g_cacheLock);
+            g_cache[key] = p;
+            return p;
+        }
+    }
+
     if (!exists(clang) || !exists(link)) {
         err = "user shader: the OpenCL C compiler is not installed (" + clang + ", llvm-link; set RDX_CLANG)";
         return nullptr;
@@ -106,15 +193,15 @@ UserProgram* compile_user_shader(const std::string& text, const std::string& inc
     { std::ofstream f(dir + "/entry.cl"); f << kEntry; }
     std::vector<std::string> common = {clang, "-x", "cl", "-cl-std=CL1.2", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + arch, "-Xclang",
                                        "-finclude-default-header", "--rocm-path=" + rocm, "-O3"};
-    // extra options, e.g. RDX_JIT_FLAGS="-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt" (the contract of the stock pipeline)
-    if (const char* extra = std::getenv("RDX_JIT_FLAGS")) {
-        std::stringstream ss(extra);
+    {
+        std::stringstream ss(fpFlags);
         std::string tok;
         while (ss >> tok) common.push_back(tok);
     }
-    auto cleanup = [&]() { if (!std::getenv("RDX_JIT_KEEP")) { std::string cmd = "rm -rf '" + dir + "'"; (void)!system(cmd.c_str()); } };
+    auto cleanup = [&]() { if (!std::getenv("RDX_JIT_KEEP")) remove_tree(dir); };
     std::vector<std::string> a = common;
     if (!includePath.empty()) a.push_back("-I" + includePath);
+    if (!ownDir.empty()) a.push_back("-I" + ownDir);
     // the printf lowering introduces a library call after the first link of the builtin bitcode
     for (const char* s : {"-Xclang", "-mlink-builtin-bitcode-postopt", "-emit-llvm", "-c"}) a.push_back(s);
     a.push_back(dir + "/user.cl"); a.push_back("-o"); a.push_back(dir + "/user.bc");
@@ -130,17 +217,13 @@ UserProgram* compile_user_shader(const std::string& text, const std::string& inc
         cleanup();
         return nullptr;
     }
-    auto* p = new UserProgram();
-    hipError_t e = hipModuleLoad(&p->module, (dir + "/user.co").c_str());
-    if (e == hipSuccess) e = hipModuleGetFunction(&p->entry, p->module, "rdx_user_entry");
-    if (e != hipSuccess) {
-        err = std::string("user shader: loading the compiled program failed: ") + hipGetErrorString(e);
-        delete p;
-        cleanup();
-        return nullptr;
-    }
+    UserProgram* p = load_code_object(dir + "/user.co", err);
+    if (!p) { cleanup(); return nullptr; }
     p->log = slurp(log);
+    if (diskCache) { (void)mkdir(cacheDir.c_str(), 0700); (void)copy_file(dir + "/user.co", cached); }
     cleanup();
+    std::lock_guard<std::mutex> lk(g_cacheLock);
+    g_cache[key] = p;
     return p;
 }
 
@@ -163,6 +246,12 @@ int launch_user_shader(UserProgram* p, hipStream_t st, void* const ptrs[12], uin
 void release_user_shader(UserProgram* p)
 {
     if (!p) return;
+    {   // programs are shared through the cache: drop the entry with the object
+        std::lock_guard<std::mutex> lk(g_cacheLock);
+        bool shared = false;
+        for (auto it = g_cache.begin(); it != g_cache.end();) { if (it->second == p) { it = g_cache.erase(it); shared = true; } else ++it; }
+        (void)shared;
+    }
     if (p->module) (void)hipModuleUnload(p->module);
     delete p;
 }

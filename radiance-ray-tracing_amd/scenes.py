@@ -461,7 +461,29 @@ def c4_atrium_10m(width=1920, height=1080, spp=4, depth=8, detail=6.3, foliage=6
     return s
 
 
-CONFIGS = {"c0_two_boxes": c0_two_boxes, "c1_cornell": c1_cornell, "c2_atrium": c2_atrium, "c4_atrium_10m": c4_atrium_10m}
+def c2_atrium_400(width=1920, height=1080, spp=4, depth=8, detail=1.0, pieces=16):
+    """The Sponza-class atrium as a loader that makes one instance per mesh would deliver it (the reference's does:
+    tools/sceneBuilder.cpp:287-315; SURVEY a5: "Sponza-class: 1 ... ~400 instances"): the same 262 k triangles, every mesh of
+    c2_atrium cut into `pieces` runs of consecutive triangles -- 25 x 16 = 400 meshes / 400 instances, identity transforms."""
+    base = c2_atrium(width, height, spp, depth, detail)
+    s = Scene("c2_atrium_400")
+    s.materials = base.materials
+    for (mi, _, mat) in base.instances:
+        v, t, n, uv = base.meshes[mi]
+        nt = t.shape[0]
+        for k in range(pieces):
+            a, b = nt * k // pieces, nt * (k + 1) // pieces
+            if b <= a:
+                continue
+            tt = t[a:b]
+            used, inv = np.unique(tt.reshape(-1), return_inverse=True)
+            s.add_instance(s.add_mesh(_finish(v[used], inv.reshape(-1, 3).astype(np.uint32), n[used], uv[used])), None, mat)
+    s.camera, s.sceneProps, s.rtprop = base.camera, base.sceneProps, base.rtprop
+    return s
+
+
+CONFIGS = {"c0_two_boxes": c0_two_boxes, "c1_cornell": c1_cornell, "c2_atrium": c2_atrium, "c4_atrium_10m": c4_atrium_10m,
+           "c2_atrium_400": c2_atrium_400}
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -925,3 +925,44 @@ def test_user_shader_program_is_compiled_and_run(mods):
     dev2 = scenes.DeviceScene(s)
     dev2.render()
     assert rd.GetTraceStats().rays_primary == 80 * 48 * 3
+
+
+def test_user_program_traces_rays_with_the_product_library(mods):
+    """A user raygen that #includes "radiance.cl" and calls traceRay() -- compiled at run time against the library's OWN device
+    library (radiance-ray-tracing_amd/shader/, no reference file on the include path) under the pinned floating-point contract
+    -- reproduces the reference's HitData bit for bit: the committed outputs of the reference's intersectTop on the 4096 rays
+    of tests/golden/refgpu_c1.npz, closest hit (sbtRecordOffset 1) and any hit (2: the program's any-hit callback ends the walk
+    at the first accepted candidate, which only decides the hit flag)."""
+    rd, scenes = mods
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import golden_cases as gc
+    import oracle_bind as ob
+    G = np.load(os.path.join(root, "tests", "golden", "refgpu_c1.npz"))
+    s = gc.small_scene(scenes, "c1")
+    text = open(os.path.join(root, "tests", "golden", "user_trace.cl")).read()
+    rd.SetShaderIncludePath("")                       # nothing but the library's own directory
+    dev = scenes.DeviceScene(s, shader_text=text)
+    o, d = np.ascontiguousarray(G["ray_o"], np.float32), np.ascontiguousarray(G["ray_d"], np.float32)
+    n = o.shape[0]
+    rays = np.concatenate([o, d], 1).reshape(-1).astype(np.float32)
+    plt = dev.plt
+    bRays = rd.CreateBuffer(plt, rays.nbytes); rd.WriteBuffer(plt, bRays, rays.nbytes, rays)
+    bOut = rd.CreateBuffer(plt, n * 28 * 4)
+    ref_h = np.ascontiguousarray(G["hits"]).view(ob.HIT_DTYPE).reshape(-1)
+    for rec in (1, 2):
+        prop = np.zeros((), rd.RayTraceProperties)
+        prop["batchSize"], prop["depth"] = n, rec
+        rd.WriteBuffer(plt, dev.rdRTProp, 16, np.array(prop))
+        rd.WriteBuffer(plt, bOut, n * 28 * 4, np.zeros(n * 28, np.uint32))
+        rd.BindDescriptorSet(plt, rd.CreateDescriptorSet([dev.rdRTProp, bOut, dev.rdImage, dev.rdCamData, dev.rdSceneData, dev.meshInfoData, bRays,
+                                                           dev.indexData, dev.uvData, dev.normalData, dev.materialData, None, None, dev.topAccelStruct]))
+        rd.TraceRays(plt, 0, 0, 0, n, 1)
+        got = rd.ReadBuffer(plt, bOut, n * 28 * 4).view(ob.HIT_DTYPE).reshape(-1)
+        if rec == 1:
+            assert np.array_equal(ref_h["hit"], got["hit"])
+            h = ref_h["hit"] == 1
+            assert h.sum() > 500
+            for f in ("distance", "primitiveIndex", "instanceIndex", "instanceCustomIndex", "instanceSBTOffset", "barycentric", "hitPoint", "transform"):
+                assert np.array_equal(_bits(ref_h[f][h]), _bits(got[f][h])), f
+        else:
+            assert np.array_equal(got["hit"].astype(np.uint8), G["shadow_hit"])
