@@ -82,6 +82,10 @@ struct PathStreams {
     float4* colLit;    // colour if the light is visible
     float4* colSh;     // colour if it is occluded
     float4* sampleColor; // [samples_in_chunk][pixels] final per-sample radiance
+    // user stage functions on the wavefront pipeline (user_shader.cpp "stage mode"; allocated only then): the shadow query's own
+    // direction and answer, and the two payload members the stock raygen carries from bounce to bounce (color, nextFactor)
+    float4* shD; uint32_t* shHit;
+    float4* payC; float4* payF; float4* nPayC; float4* nPayF;
     // per-bounce ray sort (option "sort"): the order in which the persistent traversal launch HANDS OUT the rays of this
     // bounce -- work item i is path permS[i] (shadow query) / permE[i] (next-bounce ray).  Null = identity.  Nothing is moved:
     // the streams stay in compaction order, only the waves' ray assignment follows the sort.
@@ -121,6 +125,9 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
                    uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,
                    unsigned long long* visit, uint32_t* counter);
 // shadow(d) of `psShadow` and extend(d+1) of `psExtend` (its streams already swapped) in one cooperative launch
+// any-hit walk of the shadow queries a user's closest-hit shader recorded (origin shO, direction shD per path): answer -> shHit
+void launch_shadow_user(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax, float tmin, float tmax,
+                        uint32_t* counter);
 void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& psShadow, const PathStreams& psExtend,
                   const uint32_t* mPtr, uint32_t mMax, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, uint32_t* counter);
 // whole paths (camera ray to path end) on the persistent cooperative engine, one launch per sample chunk;

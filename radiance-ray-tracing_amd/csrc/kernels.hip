@@ -974,6 +974,28 @@ struct ShadowPolicy {
     }
 };
 
+// shadow queries recorded by a user's closest-hit shader (user_shader.cpp "stage mode"): per-path origin AND direction, the
+// answer is only the flag (the row's any-hit shader ends the walk at the first accepted candidate: order-free)
+struct UserShadowPolicy {
+    PathStreams ps;
+    RDX_SINGLE_RAY_POLICY
+    __device__ __forceinline__ bool load(uint32_t i, f3& o, f3& d, bool& anyHit) const
+    {
+        const float4 so = ps.shO[i], sd = ps.shD[i];
+        o = mk3(so.x, so.y, so.z); d = mk3(sd.x, sd.y, sd.z);
+        anyHit = true;
+        return so.w != 0.0f;
+    }
+    __device__ __forceinline__ void store(uint32_t i, const Best& b, f3, f3) const { ps.shHit[i] = b.hit ? 1u : 0u; }
+};
+template <bool INL, bool CULL>
+__global__ void POOL_BOUNDS
+k_shadow_user_pool(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
+{
+    UserShadowPolicy pol{ps};
+    traverse_pool<2, INL, CULL>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+
 __global__ void COOP_BOUNDS
 k_extend_coop(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
 {
@@ -1466,6 +1488,14 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
                            lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax, visit);
 }
 
+void launch_shadow_user(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax, float tmin, float tmax,
+                        uint32_t* counter)
+{
+    if (!nMax) return;
+    size_t lds; const uint32_t th = pool_threads(av, lds);
+    RDX_POOL_LAUNCH(k_shadow_user_pool, dim3(coop_blocks(nMax, th, lds, POOL_WPE)), av, ps, nPtr, counter, tmin, tmax);
+}
+
 void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& psShadow, const PathStreams& psExtend,
                   const uint32_t* mPtr, uint32_t mMax, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax, uint32_t* counter)
 {
@@ -1564,6 +1594,59 @@ void launch_pcg3d_batch(hipStream_t st, const uint32_t* in3, float* out3, uint32
 {
     if (!n) return;
     hipLaunchKernelGGL(k_pcg3d_batch, dim3(blocks_for(n, RDX_BLOCK)), dim3(RDX_BLOCK), 0, st, in3, out3, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FETCH_SIZE calibration probe (tools/fetch_calibrate.py; bench.py's roofline)
+// ---------------------------------------------------------------------------------------------
+// rocprofv3's FETCH_SIZE is calibrated in /opt/skills/guides/MI355X_MICROARCH.md for wide coalesced reads only (it reports half
+// their bytes on gfx950).  The traversal kernels read differently: every lane gathers ONE record -- a 64-byte wide node (four
+// dwordx4) or a 48-byte triangle (three) -- at an address of its own.  This kernel does exactly that on a table of known size
+// with a known number of reads, so that the counter can be read against a known byte count for this access shape.
+// (STREAM: lane i reads 16 consecutive bytes at i -- the guide's own case, for reference.)
+template <int QUADS, bool STREAM>
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_probe_gather(const uint4* __restrict__ table, uint32_t nRecords, uint32_t nReads, uint32_t seed, uint32_t* __restrict__ sink)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (i >= nReads) return;
+    uint32_t h = i * 2654435761u + seed;             // integer hash -> record index (uniform over the table)
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    const uint32_t rec = STREAM ? i % nRecords : (uint32_t)(((unsigned long long)h * nRecords) >> 32);
+    const uint4* p = table + (size_t)rec * QUADS;
+    uint4 acc = p[0];
+#pragma unroll
+    for (int k = 1; k < QUADS; ++k) { const uint4 v = p[k]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = i;      // (keeps the loads alive; the table holds other values)
+}
+// recBytes: 64 / 48 (gathers) or 16 (streaming); returns the kernel time of the last repetition in ms, < 0 on error
+extern "C" float rdx_debug_gather_probe(uint32_t recBytes, unsigned long long tableBytes, uint32_t nReads, uint32_t reps)
+{
+    const uint32_t quads = recBytes / 16u;
+    if (quads != 4u && quads != 3u && quads != 1u) return -1.0f;
+    const uint32_t nRecords = (uint32_t)std::min<unsigned long long>(tableBytes / recBytes, 0xffffffffull);
+    if (!nRecords || !nReads) return -1.0f;
+    uint4* table = nullptr; uint32_t* sink = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&table), (size_t)nRecords * recBytes) != hipSuccess) return -1.0f;
+    if (hipMalloc(reinterpret_cast<void**>(&sink), 64) != hipSuccess) { (void)hipFree(table); return -1.0f; }
+    (void)hipMemset(table, 0x5a, (size_t)nRecords * recBytes);
+    (void)hipMemset(sink, 0, 64);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    float ms = 0.0f;
+    const dim3 grid(blocks_for(nReads, RDX_BLOCK)), block(RDX_BLOCK);
+    for (uint32_t r = 0; r < reps; ++r) {
+        (void)hipEventRecord(a, nullptr);
+        if (quads == 4u) hipLaunchKernelGGL((k_probe_gather<4, false>), grid, block, 0, nullptr, table, nRecords, nReads, 17u + r, sink);
+        else if (quads == 3u) hipLaunchKernelGGL((k_probe_gather<3, false>), grid, block, 0, nullptr, table, nRecords, nReads, 17u + r, sink);
+        else hipLaunchKernelGGL((k_probe_gather<1, true>), grid, block, 0, nullptr, table, nRecords, nReads, 17u + r, sink);
+        (void)hipEventRecord(b, nullptr);
+        if (hipEventSynchronize(b) != hipSuccess) { ms = -1.0f; break; }
+        (void)hipEventElapsedTime(&ms, a, b);
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(table); (void)hipFree(sink);
+    return ms;
 }
 
 #ifdef COOP_STATS

@@ -25,6 +25,9 @@
 #ifndef RDX_SBT_HEADER
 #define RDX_SBT_HEADER "sbt_generated.h"      // tools/genSBT.py output (the table this library's stage kernels were built for)
 #endif
+#ifndef RDX_STOCK_REDUCED_HASH
+#define RDX_STOCK_REDUCED_HASH 0xf95635133b09cb3full         // of samples/shader.cl; tools/stock_shader_hash.py prints it
+#endif
 #include RDX_SBT_HEADER
 #include "bvh_build.h"
 #include "device_math.h"
@@ -64,6 +67,7 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     bool coopOK = true;                // scene fits the key packing of the wave-cooperative kernel
     uint32_t* groupBits = nullptr;     // pool engine: instance slots of the shared-transform group (bitmap, 9 words on the device), see derive_accel
     uint32_t groupCount = 0;
+    bool groupIdentity = false;        // ... and the group's transform is the identity: root tests in the flat top-level step
     uint32_t unifiedRoot = 0, unifiedNeed = 0;   // pool engine: one tree over top level + instances + BLASes (derive_accel), 0 = not built
     void release()
     {
@@ -100,7 +104,9 @@ struct rdx_buffer_s {
 };
 struct rdx_sampler_s { uint32_t addressing = 0, filter = 0; };
 struct rdx_blas_s { std::unique_ptr<Blas> blas; };
-struct rdx_shader_s { std::string name; bool hasRaygen = false; UserProgram* program = nullptr; };   // program != null: a user's own raygen, compiled at run time
+struct rdx_shader_s { std::string name; bool hasRaygen = false;
+                      UserProgram* program = nullptr; };   // != null: a user's program, compiled at run time -- as its raygen megakernel, or
+                                                           // (program->stages) as the shade stage of the wavefront pipeline around its stage functions
 
 namespace {
 
@@ -128,6 +134,7 @@ struct Context {
         size_t cap = 0;
         uint32_t* sortBins = nullptr;       // per-bounce ray sort: histogram scratch (ray_sort_tiles_words()) and the permutation
         uint32_t* permE = nullptr; size_t permCap = 0;
+        size_t stageCap = 0;                // user stage mode: paths the extra streams (shD, shHit, payC ...) hold
         uint32_t* dCounts = nullptr;        // [0] = paths generated, [d+1] = hits of bounce d, [64+d] / [128+d] ray counters
         uint32_t* hCounts = nullptr;        // pinned
         hipStream_t s0 = nullptr, s1 = nullptr;
@@ -159,6 +166,7 @@ struct Context {
     int sortRays = -1;                      // option "sort": per-bounce ray sort: 1 on, 0 off, -1 automatic
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int groupInstances = 1;                 // pool engine: instances with bit-identical inverse matrices share one ray slot (option "group_instances")
+    int userStages = 1;                     // user programs that differ from the stock one only inside stage functions run on the wavefront pipeline (option "user_stages")
     int unifiedTree = 1;                    // pool engine: large top levels of identity instances are walked by the pool (option "unified_tree")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
@@ -543,6 +551,7 @@ int derive_accel(rdx_buffer_s* tb)
     // the ray slot; it is kept in the triangle record (DTri._p0), which needs the BLAS to belong to exactly one instance.
     // The largest such set of instances (>= 2, inner-node roots only) is the group.
     uint32_t groupBits[8] = {0, 0, 0, 0, 0, 0, 0, 0}, groupCount = 0;
+    bool groupIdentity = false;
     if (nInst <= 256) {
         std::map<std::array<uint32_t, 16>, std::vector<uint32_t>> byInv;
         for (uint32_t k = 0; k < nInst; ++k) {
@@ -554,6 +563,12 @@ int derive_accel(rdx_buffer_s* tb)
         }
         const std::vector<uint32_t>* best = nullptr;
         for (auto& kv : byInv) if (kv.second.size() >= 2 && (!best || kv.second.size() > best->size())) best = &kv.second;
+        if (best) {
+            // identity group: the group's object-space ray equals the world ray up to the sign of zeros, on which no slab decision
+            // depends -- the flat top-level step then runs the reference's root-box test of these instances itself (world ray)
+            groupIdentity = true;
+            for (int e = 0; e < 16; ++e) if (!(dI[(*best)[0]].inv[e] == ((e % 5 == 0) ? 1.0f : 0.0f))) groupIdentity = false;
+        }
         if (best)
             for (uint32_t k : *best) {
                 groupBits[k >> 5] |= 1u << (k & 31u); ++groupCount;
@@ -700,7 +715,7 @@ int derive_accel(rdx_buffer_s* tb)
     ac->blasNeedAny = maxBlasAny;
     for (int k = 0; k < 3; ++k) { ac->sceneLo[k] = tnodes[0].bottom[k]; ac->sceneHi[k] = tnodes[0].top[k]; }
     ac->sbtOffsets = sbtOffsets || hugeLeaf;      // (either way: the reference-order kernel, which reads the blob's own node layout)
-    ac->groupCount = groupCount;
+    ac->groupCount = groupCount; ac->groupIdentity = groupIdentity;
     ac->unifiedRoot = unifiedRoot; ac->unifiedNeed = unifiedNeed;
     ac->nWide = (uint32_t)dW.size();
     // per-lane kernels: [need][64 lanes] words of LDS per wave, 64 KB at most
@@ -1417,7 +1432,7 @@ static std::string strip_comments(const std::string& t)
     o.reserve(t.size());
     for (size_t i = 0; i < t.size();) {
         if (t.compare(i, 2, "//") == 0) { while (i < t.size() && t[i] != '\n') ++i; }
-        else if (t.compare(i, 2, "/*") == 0) { const size_t e = t.find("*/", i + 2); i = e == std::string::npos ? t.size() : e + 2; o.push_back(' '); }
+        else if (t.compare(i, 2, "/*") == 0) { const size_t e = t.find("*/", i + 2); const size_t j = e == std::string::npos ? t.size() : e + 2; o.push_back(' '); for (; i < j; ++i) if (t[i] == '\n') o.push_back('\n'); }
         else o.push_back(t[i++]);
     }
     return o;
@@ -1444,6 +1459,88 @@ static uint64_t fnv1a64_nows(const std::string& t)
     uint64_t h = 0xcbf29ce484222325ull;
     for (unsigned char c : t) { if (std::isspace(c)) continue; h ^= c; h *= 0x100000001b3ull; }
     return h;
+}
+
+// A program text with the BODIES of its closest-hit / miss stage functions blanked out (the functions sbt.json names for rows
+// without an any-hit shader, and the miss rows): two programs that agree on it differ only inside those functions -- the raygen
+// loop, the payload / scene structs, the helper functions, the any-hit rows and the dispatch tables are the same.
+static void blank_bodies(std::string& t, const std::vector<std::string>& names)
+{
+    for (const std::string& fn : names) {
+        size_t pos = 0;
+        while ((pos = t.find(fn, pos)) != std::string::npos) {
+            const size_t end = pos + fn.size();
+            const bool startOK = pos == 0 || !(std::isalnum((unsigned char)t[pos - 1]) || t[pos - 1] == '_');
+            size_t q = end;
+            while (q < t.size() && std::isspace((unsigned char)t[q])) ++q;
+            if (!startOK || q >= t.size() || t[q] != '(') { pos = end; continue; }
+            // parameter list, then a definition's '{' (a call or a prototype has something else there)
+            int depth = 0;
+            size_t r = q;
+            for (; r < t.size(); ++r) { if (t[r] == '(') ++depth; else if (t[r] == ')') { if (--depth == 0) { ++r; break; } } }
+            while (r < t.size() && std::isspace((unsigned char)t[r])) ++r;
+            if (r >= t.size() || t[r] != '{') { pos = end; continue; }
+            int braces = 0;
+            size_t e = r;
+            for (; e < t.size(); ++e) { if (t[e] == '{') ++braces; else if (t[e] == '}') { if (--braces == 0) { ++e; break; } } }
+            std::string blank = "{";
+            blank.append((size_t)std::count(t.begin() + r, t.begin() + e, '\n'), '\n');       // line numbers stay (compiler diagnostics)
+            blank += "}";
+            t.replace(r, e - r, blank);
+            pos = r + blank.size();
+        }
+    }
+}
+static std::string blank_stage_bodies(const std::string& text)
+{
+    std::string t = strip_comments(text);
+    std::vector<std::string> names;
+    {
+        struct Row { int row; const char* fn; };
+        static const Row anyHit[] = {
+#define X(row, fn) {row, #fn},
+            RDX_SBT_ANY_HIT(X)
+#undef X
+            {-1, nullptr}};
+        static const Row closest[] = {
+#define X(row, fn) {row, #fn},
+            RDX_SBT_CLOSEST_HIT(X)
+#undef X
+            {-1, nullptr}};
+        static const Row miss[] = {
+#define X(row, fn) {row, #fn},
+            RDX_SBT_MISS(X)
+#undef X
+            {-1, nullptr}};
+        for (const Row* c = closest; c->fn; ++c) {
+            bool hasAny = false;
+            for (const Row* a = anyHit; a->fn; ++a) if (a->row == c->row) hasAny = true;
+            if (!hasAny) names.push_back(c->fn);
+        }
+        for (const Row* m = miss; m->fn; ++m) names.push_back(m->fn);
+    }
+    blank_bodies(t, names);
+    return t;
+}
+extern "C" unsigned long long rdx_debug_stage_reduced_hash(const char* code, uint32_t size)
+{
+    return code ? fnv1a64_nows(blank_stage_bodies(std::string(code, size))) : (unsigned long long)RDX_STOCK_REDUCED_HASH;   // null: the stock program's
+}
+
+// Compile-only check of the run-time shader compiler (no device needed; the CPU suite uses it): 0 = the program compiles in
+// the given mode (stages: with its raygen body blanked, as rdx_shader_module_create does), -1 = it does not, the log in the
+// last-error string.  "Compiles" = every step up to loading the code object succeeded.
+extern "C" int rdx_debug_jit_compiles(const char* code, uint32_t size, const char* arch, int stages)
+{
+    if (!code || !arch) return fail("rdx_debug_jit_compiles: null argument");
+    std::string text(code, size), err;
+    if (stages) { text = strip_comments(text); blank_bodies(text, {"raygen", "generateRay"}); }
+    setenv("RDX_JIT_COMPILE_ONLY", "1", 1);
+    UserProgram* p = compile_user_shader(text, g0.shaderInclude, arch, stages != 0, err);
+    unsetenv("RDX_JIT_COMPILE_ONLY");
+    (void)p;
+    if (err == "compiled") return 0;
+    return fail_str(err.empty() ? std::string("rdx_debug_jit_compiles: unexpected state") : err);
 }
 
 extern "C" int rdx_shader_include_path(const char* path)
@@ -1479,7 +1576,22 @@ extern "C" rdx_shader rdx_shader_module_create(const char* code, uint32_t size, 
         std::string arch = prop.gcnArchName;
         arch = arch.substr(0, arch.find(':'));
         std::string err;
-        s->program = compile_user_shader(text, g0.shaderInclude, arch, err);
+        // 3a. the program differs from the stock one only INSIDE its closest-hit / miss stage functions (blank_stage_bodies):
+        //     those functions are compiled into the shade stage of the wavefront pipeline (user_shader.cpp "stage mode");
+        // 3b. anything else: the program's own raygen, as a megakernel.
+        constexpr uint64_t kStockReducedHash = RDX_STOCK_REDUCED_HASH;     // of samples/shader.cl, by tools/stock_shader_hash.py
+        //     "user_stages" 2: the caller asserts it for a program written from scratch (the raygen text is then not looked at).
+        const bool stages = g0.userStages == 2 || (g0.userStages == 1 && fnv1a64_nows(blank_stage_bodies(text)) == kStockReducedHash);
+        if (stages) {
+            // the stage kernel replaces the program's raygen: its body and that of the stock skeleton's camera helper go (dead
+            // code there, and their get_global_id(0) has no `sceneData` in scope for the stage-mode macro)
+            std::string t = bare;
+            blank_bodies(t, {"raygen", "generateRay"});
+            std::string err2;
+            s->program = compile_user_shader(t, g0.shaderInclude, arch, true, err2);
+            if (!s->program && g0.userStages == 2) { fail_str(err2); return nullptr; }
+        }
+        if (!s->program) s->program = compile_user_shader(text, g0.shaderInclude, arch, false, err);
         if (!s->program) { fail_str(err); return nullptr; }
     }
     g.shaders.push_back(std::move(s));
@@ -1585,6 +1697,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
     if (!strcmp(name, "group_instances")) { g.groupInstances = value != 0; return 0; }
     if (!strcmp(name, "unified_tree")) { g.unifiedTree = value != 0; return 0; }
+    if (!strcmp(name, "user_stages")) { g.userStages = value > 2 ? 1 : (int)value; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
     return fail("rdx_set_option: unknown option '%s'", name);
@@ -1622,7 +1735,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
     auto* bTlas = static_cast<rdx_buffer_s*>(g.slots[13]);
     const uint64_t nPix = (uint64_t)width * height;
     if (nPix == 0) return 0;
-    if (g.pipeline->program) {
+    if (g.pipeline->program && !g.pipeline->program->stages) {
         // a user's own raygen program: the megakernel, one work-item per pixel, bound by position like clSetKernelArg
         // (radiance.cpp:231-259); slots 11 / 12 (texture array, sampler) are passed as null descriptors
         if (nPix > 0xffffffffull) return fail("TraceRays: too many pixels");
@@ -1716,6 +1829,64 @@ static int trace_rays_device(uint32_t width, uint32_t height)
         }
         HIP_OK(hipEventRecord(g.evChunk, g.stream));          // everything before this chunk (previous accumulate) is done first
 
+        if (g.pipeline->program && g.pipeline->program->stages) {
+            // ---- a user's stage functions on the wavefront pipeline (user_shader.cpp "stage mode") --------------------------------
+            // generate -> extend(0) -> [ stage pass 0 (records the shader's shadow query) -> shadow walk -> stage pass 1 (the shader
+            // again, the query answered; raygen bookkeeping; compaction) -> extend(d + 1) ] ... -> accumulate.  One group, no fusing:
+            // extend(d + 1) needs pass 1's rays.
+            if (av.kernel != 3) return fail("TraceRays: user stage functions need the pool engine (kernel 3)");
+            Context::Group& G = g.groups[0];
+            const uint32_t n0 = sc_n * P;
+            if (ensure_group(G, n0)) return -1;
+            if (G.stageCap < n0) {
+                float4** arr[] = {&G.ps.shD, &G.ps.payC, &G.ps.payF, &G.ps.nPayC, &G.ps.nPayF};
+                for (auto a : arr) { if (*a) HIP_IGN(hipFree(*a)); *a = nullptr; HIP_OK(hipMalloc(reinterpret_cast<void**>(a), (size_t)n0 * sizeof(float4))); }
+                if (G.ps.shHit) HIP_IGN(hipFree(G.ps.shHit));
+                G.ps.shHit = nullptr;
+                HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.ps.shHit), (size_t)n0 * sizeof(uint32_t)));
+                G.stageCap = n0;
+            }
+            G.ps.sampleColor = g.sampleColor;
+            PathStreams ps = G.ps;
+            std::memset(G.hCounts, 0, 256 * sizeof(uint32_t));
+            G.hCounts[0] = n0;
+            HIP_OK(hipMemcpyAsync(G.dCounts, G.hCounts, 256 * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+            launch_generate(g.stream, C, ps, owned, P, s0, sc_n, rt.totalSamples);
+            if (maxDepth == 0) launch_finalize_all(g.stream, ps, n0, P, sampleBase);
+            else launch_extend(g.stream, av, ps, G.dCounts, n0, tmin, tmax, nullptr, G.dCounts + 64);
+            void* slotPtr[14];
+            for (int i = 0; i < 14; ++i) slotPtr[i] = (g.slots[i] && known_buffer(g.slots[i])) ? dp(static_cast<rdx_buffer_s*>(g.slots[i])) : nullptr;
+            for (uint32_t d = 0; d < maxDepth; ++d) {
+                for (uint32_t pass = 0; pass < 2; ++pass) {
+                    const uint32_t scalars[6] = {pass, d, maxDepth, P, sampleBase, rt.debug};
+                    void* ptrs[31] = {G.dCounts + d, G.dCounts + d + 1, G.dCounts + 200,
+                                      slotPtr[3], slotPtr[4], slotPtr[5], slotPtr[6], slotPtr[7], slotPtr[8], slotPtr[9], slotPtr[10], slotPtr[13],
+                                      const_cast<DInst*>(av.insts),
+                                      ps.rayO, ps.rayD, ps.thr, ps.col, ps.hitA, ps.hitInst, ps.payC, ps.payF,
+                                      ps.shO, ps.shD, ps.shHit,
+                                      ps.nRayO, ps.nRayD, ps.nThr, ps.nCol, ps.nPayC, ps.nPayF, ps.sampleColor};
+                    std::string err;
+                    if (launch_user_stage(g.pipeline->program, g.stream, scalars, ptrs, n0, err)) return fail_str(err);
+                    if (pass == 0) launch_shadow_user(g.stream, av, ps, G.dCounts + d, n0, tmin, tmax, G.dCounts + 128 + d);
+                }
+                std::swap(ps.rayO, ps.nRayO); std::swap(ps.rayD, ps.nRayD); std::swap(ps.thr, ps.nThr); std::swap(ps.col, ps.nCol);
+                std::swap(ps.payC, ps.nPayC); std::swap(ps.payF, ps.nPayF);
+                if (d + 1 < maxDepth) launch_extend(g.stream, av, ps, G.dCounts + d + 1, n0, tmin, tmax, nullptr, G.dCounts + 64 + d + 1);
+            }
+            launch_accumulate(g.stream, ps, owned, P, s0, sc_n, rt.totalSamples, s0 + sc_n >= batch, rt.debug,
+                              static_cast<float*>(dp(bScratch)), static_cast<uint8_t*>(dp(bImage)));
+            HIP_OK(hipMemcpyAsync(G.hCounts, G.dCounts, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, g.stream));
+            HIP_OK(hipStreamSynchronize(g.stream));
+            if (G.hCounts[200] != 0)
+                return fail("TraceRays: the program's closest-hit shader cannot run on the wavefront pipeline (%s); rdx_set_option(\"user_stages\", 0) runs it as a megakernel",
+                            (G.hCounts[200] & 4u) ? "it calls traceRay more than once" : "its nested traceRay is not the stock shadow query: sbtRecordOffset 2, Tmin 0.001, Tmax 1000");
+            const uint32_t* hc = G.hCounts;
+            if (maxDepth) g.stats.rays_primary += hc[0];
+            for (uint32_t d = 1; d < maxDepth; ++d) g.stats.rays_bounce += hc[d];
+            for (uint32_t d = 0; d <= maxDepth && maxDepth; ++d) g.bounceCounts[d] += hc[d];
+            g.stats.launches_extend += maxDepth; g.stats.launches_shadow += maxDepth;
+            continue;
+        }
         if (g.pathMode == 1 && !visit && av.kernel == 3 && maxDepth > 0) {
             // ---- whole paths in one persistent launch (k_path_pool) + accumulate ----
             Context::Group& G = g.groups[0];

@@ -174,6 +174,56 @@ bool intersectTop(__global const struct AccelStruct* accelStruct, float3 origin,
     return any;
 }
 
+#ifdef RDX_WAVEFRONT_STAGES
+/* ---- stage mode (csrc/user_stages.cpp): the user's closest-hit / miss functions run inside the wavefront pipeline ------------
+ * The pipeline's own kernels trace; a hit shader that calls traceRay itself (the stock `material` asks for a shadow ray in the
+ * middle of the function, shader.cl:499-509) is run TWICE around that traversal stage: pass 0 RECORDS the query -- traceRay
+ * notes origin / direction / bounds / SBT indices and answers "miss" so that the shader runs to its end; its output is
+ * dropped -- pass 1 REPLAYS it: traceRay answers with what the traversal stage found and dispatches the hit or the miss
+ * callback as the megakernel's traceRay would.  Shaders are pure functions of their inputs (the RNG is a hash of frame, pixel,
+ * depth), so pass 1 computes exactly what the megakernel computes.  The context travels in front of the SceneData object the
+ * stage kernel hands to the shader -- the one pointer a shader passes on to traceRay unchanged. */
+struct RdxStageCtx {
+    uint mode;                  /* 0 record, 1 replay */
+    uint calls;                 /* nested traceRay calls of this shader invocation */
+    uint answer;                /* replay: the recorded query found a candidate */
+    uint error;                 /* 1: a second nested trace; 2: a query the traversal stage cannot serve */
+    float4 origin;              /* recorded query: origin | Tmin */
+    float4 direction;           /* direction | Tmax */
+    int sbtRecordOffset, missIndex;
+    uint pixel;                 /* what get_global_id(0) is in the megakernel: the pixel this path belongs to */
+    uint pad1;
+};
+#define RDX_STAGE_CTX(sd) ((struct RdxStageCtx*)(((char*)(sd)) - sizeof(struct RdxStageCtx)))
+/* The stage kernel's work-items are compacted paths, not pixels; the user's text is compiled with
+ * `#define get_global_id(d) rdx_stage_gid((d), sceneData)` (user_shader.cpp), which works wherever the stage functions' own
+ * `sceneData` parameter is in scope -- as in the stock shader (shader.cl:522) -- and otherwise fails to compile, upon which the
+ * runtime falls back to the megakernel. */
+#define rdx_stage_gid(d, sd) ((size_t)((d) == 0 ? RDX_STAGE_CTX(sd)->pixel : 0u))
+
+void traceRay(__global struct AccelStruct* topLevel, int sbtRecordOffset, int missIndex,
+              float3 origin, float3 direction, float Tmin, float Tmax,
+              struct Payload* payload, struct SceneData* sceneData, image2d_array_t imageArray, sampler_t sampler)
+{
+    struct RdxStageCtx* c = RDX_STAGE_CTX(sceneData);
+    c->calls++;
+    if (c->calls > 1u) { c->error = 1u; callMiss(missIndex, payload, sceneData, imageArray, sampler); return; }
+    if (c->mode == 0u) {
+        c->origin = (float4)(origin, Tmin);
+        c->direction = (float4)(direction, Tmax);
+        c->sbtRecordOffset = sbtRecordOffset; c->missIndex = missIndex;
+        callMiss(missIndex, payload, sceneData, imageArray, sampler);
+        return;
+    }
+    if (c->answer) {
+        /* an any-hit-terminated query: which candidate ended the walk is not recorded (the stock `shadow` does not look) */
+        struct HitData hd;
+        hd.hitPoint = (float3)(0.0f); hd.distance = 0.0f; hd.primitiveIndex = 0u; hd.instanceIndex = 0u; hd.instanceCustomIndex = 0u;
+        hd.instanceSBTOffset = 0u; hd.barycentric = (float3)(0.0f); hd.transform = (mat4x4)(0.0f);
+        callHit(sbtRecordOffset, payload, &hd, sceneData, imageArray, sampler);
+    } else callMiss(missIndex, payload, sceneData, imageArray, sampler);
+}
+#else
 /* closest hit over the whole scene, then the hit or the miss callback (radiance.cl:254-275) */
 void traceRay(__global struct AccelStruct* topLevel, int sbtRecordOffset, int missIndex,
               float3 origin, float3 direction, float Tmin, float Tmax,
@@ -186,5 +236,6 @@ void traceRay(__global struct AccelStruct* topLevel, int sbtRecordOffset, int mi
     else
         callMiss(missIndex, payload, sceneData, imageArray, sampler);
 }
+#endif
 
 #endif

@@ -18,7 +18,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
-CO = {"p": os.path.join(REF_DIR, "ref_shader_gfx950_p.co"), "d": os.path.join(REF_DIR, "ref_shader_gfx950_d.co")}
+CO = {"p": os.path.join(REF_DIR, "ref_shader_gfx950_p.co"), "d": os.path.join(REF_DIR, "ref_shader_gfx950_d.co"),
+      "um": os.path.join(REF_DIR, "ref_shader_gfx950_um.co")}      # um: the reference program with tests/golden/user_material.inc as `material`
 
 HIT_WORDS, PAYLOAD_WORDS = 28, 13
 _hip = None

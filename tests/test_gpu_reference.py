@@ -170,6 +170,39 @@ def test_full_size_frames_identical_to_reference(mods, ref, cfg, cull):
     print("%s: reference kernel %.0f ms, product %.1f ms per frame" % (cfg, t[0][0], t[0][1]))
 
 
+def user_stage_program():
+    """tests/golden/user_stages.cl with its closest-hit body spliced in (what the C preprocessor would do with the #include)"""
+    text = open(os.path.join(GOLD, "user_stages.cl")).read()
+    return text.replace('#include "user_material.inc"', open(os.path.join(GOLD, "user_material.inc")).read())
+
+
+@pytest.mark.parametrize("cfg,kw", [("c1_cornell", dict(width=480, height=270, spp=3, depth=6, sphere_subdiv=3)),
+                                    ("c2_atrium", dict(width=480, height=270, spp=2, depth=8, detail=0.5))])
+def test_user_closest_hit_shader_on_the_wavefront_pipeline(mods, cfg, kw):
+    """A user's own closest-hit shader (tests/golden/user_material.inc: a shadow query in the middle of the function, the
+    per-pixel RNG, next ray, throughput) runs on the wavefront pipeline -- compiled at run time, recorded / replayed around the
+    pipeline's shadow-walk stage (csrc/user_shader.cpp "stage mode") -- and the frame equals, bit for bit, the REFERENCE
+    program's megakernel with that same function body in the place of its `material` (oracle/patch_material.py ->
+    oracle/_ref/ref_shader_gfx950_um.co): imageScratch and RGBA8, three progressive TraceRays calls."""
+    rd, scenes = mods
+    if not rg.available("um"):
+        pytest.skip("oracle/_ref/ref_shader_gfx950_um.co is not built (needs /root/reference: `make -C oracle`)")
+    refum = rg.RefGpu("um")
+    s = getattr(scenes, cfg)(**kw)
+    rd.SetShaderIncludePath("")
+    rd.SetOption("user_stages", 2)
+    try:
+        dev = scenes.DeviceScene(s, shader_text=user_stage_program())
+    finally:
+        rd.SetOption("user_stages", 1)
+    blob = rd.ReadBuffer(dev.plt, dev.topAccelStruct, dev.topAccelStruct.size).tobytes()
+    rs = rg.RefScene(refum, s, blob)
+    t = _frames_identical(rd, dev, rs, frames=3)
+    st = rd.GetTraceStats()
+    assert st.launches_extend >= kw["depth"] and st.launches_shadow == st.launches_extend, "the program did not run on the wavefront pipeline"
+    print("%s with a user closest-hit shader: reference megakernel %.0f ms, product stage mode %.1f ms per frame" % (cfg, t[0][0], t[0][1]))
+
+
 def test_many_instance_scene_identical_to_reference(mods, ref):
     """The Sponza-class scene as a one-instance-per-mesh loader delivers it (tools/sceneBuilder.cpp:287-315): 400 instances,
     a top level of ~200 nodes -- too large for the flat top-level step, so the pool engine walks top level, instances and BLASes
