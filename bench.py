@@ -15,8 +15,9 @@ are such frames) is timed as well and reported under `also.weak_scaling_n_x_spp`
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline      dominant kernel (k_fused_pool = shadow rays of bounce d + closest-hit rays of bounce d+1 per launch).
                 `achieved` = fabric bytes per launch (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of this same workload,
-                collected by this run in child processes after the timed region, corrected as
-                /opt/skills/guides/MI355X_MICROARCH.md prescribes) / the kernel's average launch duration (HIP events on
+                collected by this run in child processes after the timed region; units as
+                /opt/skills/guides/MI355X_MICROARCH.md prescribes, FETCH_SIZE at face value as calibrated for this kernel's
+                record gathers by tools/fetch_calibrate.py) / the kernel's average launch duration (HIP events on
                 the library's own stream inside the timed region), against the 8 TB/s HBM peak -- a fraction that cannot
                 exceed 1.  The SURVEY 8(d) byte model (every visit of the REFERENCE's exhaustive walk charged as an
                 uncached read) is kept beside it as `reference_walk_equiv_GBps`: a throughput normalisation without a
@@ -209,14 +210,23 @@ def measured_roofline(kernel_name, launches_s, launches, child_args):
     out = {"traffic": None, "achieved": None, "issue": None}
     f, w = res.get("fetch"), res.get("write")
     if f and w and avg_s > 0:
-        # guide: both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B -> doubled (calibrated for
-        # wide coalesced reads, uncalibrated for other widths: an upper estimate for this kernel's 16-B-per-lane gathers)
-        rd_b = f["FETCH_SIZE"] * 1024.0 * 2.0
+        # guide: both counters are in KiB; on gfx950 FETCH_SIZE tallies wide coalesced reads (128-B requests) at 64 B, hence its
+        # "x 2".  That correction is calibrated for streaming reads only; the guide says to calibrate other shapes on a known
+        # byte count.  tools/fetch_calibrate.py did (profiles/r03_fetch_calibrate.log, librdx probe kernel, one record per lane
+        # at a random index): streaming 16 B/lane reports 0.50 of the requested bytes (the guide's case), per-lane gathers of
+        # aligned 64-B records report 1.00 of them (HBM- and Infinity-Cache-resident tables alike; an L2-resident table reports
+        # ~0: the counter is L2-miss traffic), gathers of 48-B records report 80 B per record (the 32-B sectors they touch).
+        # This kernel's reads are such gathers (64-B wide nodes, 48-B triangle records), so its traffic is the counter at face
+        # value; the x 2 figure is kept as the upper bound it would be if every read were a wide coalesced one.
+        rd_b = f["FETCH_SIZE"] * 1024.0
         wr_b = w["WRITE_SIZE"] * 1024.0
         out["traffic"] = int(rd_b + wr_b)
         out["achieved"] = (rd_b + wr_b) / avg_s / 1e9
         out["traffic_detail"] = {"FETCH_SIZE_KiB_per_launch_raw": round(f["FETCH_SIZE"], 1), "WRITE_SIZE_KiB_per_launch": round(w["WRITE_SIZE"], 1),
-                                 "read_bytes_x2": int(rd_b), "write_bytes": int(wr_b),
+                                 "read_bytes": int(rd_b), "write_bytes": int(wr_b),
+                                 "read_bytes_if_all_reads_were_wide_coalesced_x2": int(2 * rd_b),
+                                 "fetch_size_calibration": "per-lane 64-B record gathers: counter = requested bytes x 1.00; 48-B records: 80 B each; "
+                                                           "streaming 16 B/lane: x 0.50 (profiles/r03_fetch_calibrate.log)",
                                  "launches_profiled": int(f["launches"]),
                                  "source": "rocprofv3 --pmc passes run by this bench.py invocation (child processes, after the timed region)"}
     q = res.get("issue")
@@ -532,9 +542,10 @@ def main():
         "config": {"workload": workload_label(args.workload, args, spp_main), "width": args.width, "height": args.height, "spp": spp_main, "depth": args.depth,
                    "spp_per_gpu_equivalent": args.spp,
                    "sharding": "none" if world == 1 else "64x64 image tiles interleaved over %d ranks + RGBA8 gather" % world,
-                   "traversal": "culled walk (option cull, automatic for this scene): skips only subtrees / leaves that provably cannot change the result "
-                                "(error bound in DESIGN.md 4.1c); verified bit-identical to the reference's own device code on the test corpus "
-                                "(tests/test_gpu_reference.py, tests/test_gpu_cull.py); cull=0 is the exhaustive walk",
+                   "traversal": "pool engine, exhaustive walk: every node whose ancestors' boxes the ray passes is visited, as in the reference "
+                                "(the culled walk -- docs/CULLED_WALK.md -- is automatic only for scenes of >= 1 M inner BVH nodes, i.e. the "
+                                "10.4 M-triangle workload under `also`; option cull forces it); verified bit-identical to the reference's own "
+                                "device code (tests/test_gpu_reference.py, tests/test_gpu_cull.py)",
                    # sample groups traced concurrently on their own streams (library rule: 2 for chunks of <= 4.7 M paths);
                    # with more than one, the per-launch durations behind `roofline` overlap in time
                    "sample_groups": acc.get("groups", 1)},
@@ -554,7 +565,8 @@ def main():
             # to read for the same rays.  No peak, no fraction: the product neither makes those visits nor misses the caches.
             "reference_walk_bytes_per_launch": int(roof_bytes * steps / launches),
             "reference_walk_equiv_GBps": round(ref_equiv, 2),
-            "note": "achieved = fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, KiB, PMC child passes of this run) / average "
+            "note": "achieved = fabric bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB, PMC child passes of this run; FETCH_SIZE at face "
+                    "value as calibrated for this kernel's 64-B / 48-B record gathers, see traffic_detail) / average "
                     "launch duration (HIP events in the timed region).  The scene (BVH 25 MB) lives in L2 + Infinity Cache, so "
                     "the kernel is bound by instruction issue, not by HBM: see `issue` and DESIGN.md section 5",
         },

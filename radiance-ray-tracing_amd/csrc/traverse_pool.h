@@ -786,6 +786,13 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                         if (rd1 & WIDE_LEAF) { cntR = wide_count(rd1); stR = wide_slot(rd0); }
                         else if (slab_fast(Q, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z))) pushR = rd0;
                     }
+#ifdef POOL_EXP_DOUBLE_SLAB       // experiment: what do two more slab tests cost? (results unchanged: ra.w never holds that pattern)
+                    {
+                        const bool x1 = slab_fast(Q, mk3(l0.y, l0.z, l0.x), mk3(l1.y, l1.z, l1.x));
+                        const bool x2 = slab_fast(Q, mk3(r0.y, r0.z, r0.x), mk3(r1.y, r1.z, r1.x));
+                        delta += (int)((uint32_t)x1 & (uint32_t)x2 & (uint32_t)(__float_as_uint(ra.w) == 0x12345678u));
+                    }
+#endif
                     delta += (pushL != COOP_NONE ? 1 : 0) + (pushR != COOP_NONE ? 1 : 0);
                 }
             }

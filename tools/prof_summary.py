@@ -61,13 +61,17 @@ def main():
             "launches_write_pass": write.get(k, {}).get("launches", 0),
             "FETCH_SIZE_KiB_per_launch_raw": round(f, 1),
             "WRITE_SIZE_KiB_per_launch": round(w, 1),
-            "hbm_read_bytes_per_launch_corrected_x2": int(f * 1024 * 2),
-            "hbm_write_bytes_per_launch": int(w * 1024),
-            "hbm_bytes_per_launch": int(f * 1024 * 2 + w * 1024),
+            # calibration for this code's access shapes: profiles/r03_fetch_calibrate.log (64-B record gathers: counter at face
+            # value; wide coalesced streams: x 2).  Traversal kernels gather, stream kernels (generate / shade / accumulate) stream.
+            "read_bytes_per_launch_gather_calibration_x1": int(f * 1024),
+            "read_bytes_per_launch_stream_calibration_x2": int(f * 1024 * 2),
+            "write_bytes_per_launch": int(w * 1024),
+            "bytes_per_launch_gather_calibration": int(f * 1024 + w * 1024),
+            "bytes_per_launch_stream_calibration": int(f * 1024 * 2 + w * 1024),
         }
     with open(os.path.join(out, "%s_pmc_hbm.json" % tag), "w") as fjs:
-        json.dump({"workload": workload, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled "
-                           "per the gfx950 calibration for wide coalesced reads (uncalibrated for other widths)",
+        json.dump({"workload": workload, "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE counts wide coalesced "
+                           "streams at half their bytes (guide) and per-lane 64-B record gathers at face value (tools/fetch_calibrate.py): both given",
                    "kernels": summ}, fjs, indent=1)
     # instruction-issue and cache counters (separate passes), averages per launch
     extra = {}

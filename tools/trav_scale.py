@@ -22,8 +22,9 @@ d2 = rng.normal(size=hp.shape).astype(np.float32); d2 /= np.linalg.norm(d2, axis
 o2 = (hp + 1e-3 * d2).astype(np.float32)
 perm = rng.permutation(o2.shape[0])
 o2, d2 = o2[perm], d2[perm]
-for n in (64, 1024, 16384, 65536, 262144, 1048576, o2.shape[0]):
-    for kernel in (2, 0):
+kernels = [int(k) for k in sys.argv[2].split(',')] if len(sys.argv) > 2 else [3]
+for n in (1, 64, 1024, 16384, 65536, 131072, 262144, 524288, 1048576, o2.shape[0]):
+    for kernel in kernels:
         rd.SetOption("kernel", kernel)
         ts = []
         for _ in range(5):
