@@ -187,6 +187,9 @@ def apply_options(rd, args):
         rd.SetOption("cull", args.cull)
     if args.sort >= 0:
         rd.SetOption("sort", args.sort)
+    for kv in (args.opt or "").split(","):          # experiments: any library option by name
+        if kv:
+            rd.SetOption(kv.split("=")[0], int(kv.split("=")[1]))
     if args.kernel >= 0:
         rd.SetOption("kernel", args.kernel)
         ENGINE = "pool" if args.kernel == 3 else "coop"
@@ -195,7 +198,7 @@ def apply_options(rd, args):
 def option_args(args):
     out = ["--workload", args.workload, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp),
            "--depth", str(args.depth), "--fuse", str(args.fuse), "--pipeline", str(args.pipeline), "--kernel", str(args.kernel),
-           "--top-flat", str(args.top_flat), "--groups", str(args.groups), "--cull", str(args.cull), "--sort", str(args.sort)]
+           "--top-flat", str(args.top_flat), "--groups", str(args.groups), "--cull", str(args.cull), "--sort", str(args.sort)] + (["--opt", args.opt] if args.opt else [])
     return out
 
 
@@ -357,6 +360,7 @@ def main():
     ap.add_argument("--groups", type=int, default=-1, help="-1 library default; 1..4 sample groups of a chunk on their own streams")
     ap.add_argument("--cull", type=int, default=-1, help="-1 library default (automatic); 0 = exhaustive walk, 1 = culled walk (pool engine)")
     ap.add_argument("--sort", type=int, default=-1, help="-1 library default (automatic); 0 / 1: per-bounce ray sort off / on")
+    ap.add_argument("--opt", default=None, help="comma list name=value of library options (rdx_set_option) for experiments")
     ap.add_argument("--also", default=None, help="comma list of extra workloads to time (reported under 'also'); default at N=1: the other two")
     args = ap.parse_args()
 

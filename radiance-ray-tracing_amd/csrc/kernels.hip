@@ -1619,11 +1619,77 @@ k_probe_gather(const uint4* __restrict__ table, uint32_t nRecords, uint32_t nRea
     for (int k = 1; k < QUADS; ++k) { const uint4 v = p[k]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = i;      // (keeps the loads alive; the table holds other values)
 }
+// Quad-cooperative gather of 64-byte records: the four lanes of a quad fetch, with ONE 16-byte load each, the record that one
+// of them wants -- four loads serve the four lanes -- and a 4 x 4 transpose inside the quad (DPP quad_perm, no LDS) gives every
+// lane its own record.  A per-lane gather makes the texture addresser look up 64 different cache lines per load instruction
+// (256 per 64 records); here a load instruction touches 16 lines (64 per 64 records).
+template <int C> __device__ __forceinline__ uint32_t quad_from(uint32_t v)      // value of lane (own + C) & 3 of the quad
+{
+    constexpr int ctrl = ((0 + C) & 3) | (((1 + C) & 3) << 2) | (((2 + C) & 3) << 4) | (((3 + C) & 3) << 6);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false);
+}
+template <int J> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // value of lane J of the quad
+{
+    constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint4 sel4(uint32_t k, const uint4& a, const uint4& b, const uint4& c, const uint4& d)   // k = 0..3
+{
+    const bool b0 = (k & 1u) != 0u, b1 = (k & 2u) != 0u;
+    uint4 r;
+    r.x = b1 ? (b0 ? d.x : c.x) : (b0 ? b.x : a.x); r.y = b1 ? (b0 ? d.y : c.y) : (b0 ? b.y : a.y);
+    r.z = b1 ? (b0 ? d.z : c.z) : (b0 ? b.z : a.z); r.w = b1 ? (b0 ? d.w : c.w) : (b0 ? b.w : a.w);
+    return r;
+}
+// out[c] = 16-byte piece c of the 64-byte record at index `rec` (per lane) of `table` (records of 4 uint4)
+__device__ __forceinline__ void quad_gather64(const uint4* __restrict__ table, uint32_t rec, uint4 out[4])
+{
+    const uint32_t q = __lane_id() & 3u;
+    // load j: the quad fetches the record of its lane j; lane q takes piece (q - j) & 3
+    const uint4 v0 = table[(size_t)quad_bcast<0>(rec) * 4u + ((q - 0u) & 3u)];
+    const uint4 v1 = table[(size_t)quad_bcast<1>(rec) * 4u + ((q - 1u) & 3u)];
+    const uint4 v2 = table[(size_t)quad_bcast<2>(rec) * 4u + ((q - 2u) & 3u)];
+    const uint4 v3 = table[(size_t)quad_bcast<3>(rec) * 4u + ((q - 3u) & 3u)];
+    // piece c of lane j's record sits in lane (j + c) & 3, register v[j]: that lane presents v[(own - c) & 3]
+    const uint4 t0 = sel4((q - 0u) & 3u, v0, v1, v2, v3), t1 = sel4((q - 1u) & 3u, v0, v1, v2, v3);
+    const uint4 t2 = sel4((q - 2u) & 3u, v0, v1, v2, v3), t3 = sel4((q - 3u) & 3u, v0, v1, v2, v3);
+    out[0] = t0;
+    out[1] = make_uint4(quad_from<1>(t1.x), quad_from<1>(t1.y), quad_from<1>(t1.z), quad_from<1>(t1.w));
+    out[2] = make_uint4(quad_from<2>(t2.x), quad_from<2>(t2.y), quad_from<2>(t2.z), quad_from<2>(t2.w));
+    out[3] = make_uint4(quad_from<3>(t3.x), quad_from<3>(t3.y), quad_from<3>(t3.z), quad_from<3>(t3.w));
+}
+__global__ void __launch_bounds__(RDX_BLOCK)
+k_probe_gather_quad(const uint4* __restrict__ table, uint32_t nRecords, uint32_t nReads, uint32_t seed, uint32_t* __restrict__ sink)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;       // (nReads is a multiple of the block size: all lanes take part)
+    uint32_t h = i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    const uint32_t rec = (uint32_t)(((unsigned long long)h * nRecords) >> 32);
+    uint4 o[4];
+    quad_gather64(table, rec, o);
+    // check: every piece must be the one a per-lane gather would have read (the table holds record * 4 + piece in .x when
+    // seed & 0x80000000 asks for the check)
+    uint32_t acc = o[0].x ^ o[0].y ^ o[0].z ^ o[0].w ^ o[1].x ^ o[1].y ^ o[1].z ^ o[1].w ^ o[2].x ^ o[2].y ^ o[2].z ^ o[2].w ^ o[3].x ^ o[3].y ^ o[3].z ^ o[3].w;
+    if (seed & 0x80000000u) {
+        bool ok = true;
+        for (int c = 0; c < 4; ++c) ok = ok && o[c].x == rec * 4u + (uint32_t)c && o[c].y == ~(rec * 4u + (uint32_t)c);
+        if (!ok) atomicAdd(sink + 1, 1u);
+    }
+    if (acc == 0x9e3779b9u) sink[0] = i;
+}
+__global__ void __launch_bounds__(RDX_BLOCK) k_probe_fill(uint4* __restrict__ table, uint32_t nQuads)
+{
+    const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
+    if (i < nQuads) table[i] = make_uint4(i, ~i, 0x5a5a5a5au, 0xa5a5a5a5u);
+}
 // recBytes: 64 / 48 (gathers) or 16 (streaming); returns the kernel time of the last repetition in ms, < 0 on error
 extern "C" float rdx_debug_gather_probe(uint32_t recBytes, unsigned long long tableBytes, uint32_t nReads, uint32_t reps)
 {
+    const bool coop = recBytes == 65u;            // 65: 64-byte records fetched by the quad-cooperative gather (checked against the table)
+    if (coop) recBytes = 64u;
     const uint32_t quads = recBytes / 16u;
     if (quads != 4u && quads != 3u && quads != 1u) return -1.0f;
+    if (coop) nReads &= ~(uint32_t)(RDX_BLOCK - 1);
     const uint32_t nRecords = (uint32_t)std::min<unsigned long long>(tableBytes / recBytes, 0xffffffffull);
     if (!nRecords || !nReads) return -1.0f;
     uint4* table = nullptr; uint32_t* sink = nullptr;
@@ -1631,13 +1697,15 @@ extern "C" float rdx_debug_gather_probe(uint32_t recBytes, unsigned long long ta
     if (hipMalloc(reinterpret_cast<void**>(&sink), 64) != hipSuccess) { (void)hipFree(table); return -1.0f; }
     (void)hipMemset(table, 0x5a, (size_t)nRecords * recBytes);
     (void)hipMemset(sink, 0, 64);
+    if (coop) hipLaunchKernelGGL(k_probe_fill, dim3(blocks_for(nRecords * 4u, RDX_BLOCK)), dim3(RDX_BLOCK), 0, nullptr, table, nRecords * 4u);
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     float ms = 0.0f;
     const dim3 grid(blocks_for(nReads, RDX_BLOCK)), block(RDX_BLOCK);
     for (uint32_t r = 0; r < reps; ++r) {
         (void)hipEventRecord(a, nullptr);
-        if (quads == 4u) hipLaunchKernelGGL((k_probe_gather<4, false>), grid, block, 0, nullptr, table, nRecords, nReads, 17u + r, sink);
+        if (coop) hipLaunchKernelGGL(k_probe_gather_quad, grid, block, 0, nullptr, table, nRecords, nReads, (17u + r) | 0x80000000u, sink);
+        else if (quads == 4u) hipLaunchKernelGGL((k_probe_gather<4, false>), grid, block, 0, nullptr, table, nRecords, nReads, 17u + r, sink);
         else if (quads == 3u) hipLaunchKernelGGL((k_probe_gather<3, false>), grid, block, 0, nullptr, table, nRecords, nReads, 17u + r, sink);
         else hipLaunchKernelGGL((k_probe_gather<1, true>), grid, block, 0, nullptr, table, nRecords, nReads, 17u + r, sink);
         (void)hipEventRecord(b, nullptr);
@@ -1645,6 +1713,10 @@ extern "C" float rdx_debug_gather_probe(uint32_t recBytes, unsigned long long ta
         (void)hipEventElapsedTime(&ms, a, b);
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (coop) {
+        uint32_t bad[2] = {0, 0};
+        if (hipMemcpy(bad, sink, 8, hipMemcpyDeviceToHost) != hipSuccess || bad[1] != 0u) ms = -2.0f;      // a lane got a wrong piece
+    }
     (void)hipFree(table); (void)hipFree(sink);
     return ms;
 }
