@@ -1619,45 +1619,6 @@ k_probe_gather(const uint4* __restrict__ table, uint32_t nRecords, uint32_t nRea
     for (int k = 1; k < QUADS; ++k) { const uint4 v = p[k]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = i;      // (keeps the loads alive; the table holds other values)
 }
-// Quad-cooperative gather of 64-byte records: the four lanes of a quad fetch, with ONE 16-byte load each, the record that one
-// of them wants -- four loads serve the four lanes -- and a 4 x 4 transpose inside the quad (DPP quad_perm, no LDS) gives every
-// lane its own record.  A per-lane gather makes the texture addresser look up 64 different cache lines per load instruction
-// (256 per 64 records); here a load instruction touches 16 lines (64 per 64 records).
-template <int C> __device__ __forceinline__ uint32_t quad_from(uint32_t v)      // value of lane (own + C) & 3 of the quad
-{
-    constexpr int ctrl = ((0 + C) & 3) | (((1 + C) & 3) << 2) | (((2 + C) & 3) << 4) | (((3 + C) & 3) << 6);
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false);
-}
-template <int J> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)     // value of lane J of the quad
-{
-    constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false);
-}
-__device__ __forceinline__ uint4 sel4(uint32_t k, const uint4& a, const uint4& b, const uint4& c, const uint4& d)   // k = 0..3
-{
-    const bool b0 = (k & 1u) != 0u, b1 = (k & 2u) != 0u;
-    uint4 r;
-    r.x = b1 ? (b0 ? d.x : c.x) : (b0 ? b.x : a.x); r.y = b1 ? (b0 ? d.y : c.y) : (b0 ? b.y : a.y);
-    r.z = b1 ? (b0 ? d.z : c.z) : (b0 ? b.z : a.z); r.w = b1 ? (b0 ? d.w : c.w) : (b0 ? b.w : a.w);
-    return r;
-}
-// out[c] = 16-byte piece c of the 64-byte record at index `rec` (per lane) of `table` (records of 4 uint4)
-__device__ __forceinline__ void quad_gather64(const uint4* __restrict__ table, uint32_t rec, uint4 out[4])
-{
-    const uint32_t q = __lane_id() & 3u;
-    // load j: the quad fetches the record of its lane j; lane q takes piece (q - j) & 3
-    const uint4 v0 = table[(size_t)quad_bcast<0>(rec) * 4u + ((q - 0u) & 3u)];
-    const uint4 v1 = table[(size_t)quad_bcast<1>(rec) * 4u + ((q - 1u) & 3u)];
-    const uint4 v2 = table[(size_t)quad_bcast<2>(rec) * 4u + ((q - 2u) & 3u)];
-    const uint4 v3 = table[(size_t)quad_bcast<3>(rec) * 4u + ((q - 3u) & 3u)];
-    // piece c of lane j's record sits in lane (j + c) & 3, register v[j]: that lane presents v[(own - c) & 3]
-    const uint4 t0 = sel4((q - 0u) & 3u, v0, v1, v2, v3), t1 = sel4((q - 1u) & 3u, v0, v1, v2, v3);
-    const uint4 t2 = sel4((q - 2u) & 3u, v0, v1, v2, v3), t3 = sel4((q - 3u) & 3u, v0, v1, v2, v3);
-    out[0] = t0;
-    out[1] = make_uint4(quad_from<1>(t1.x), quad_from<1>(t1.y), quad_from<1>(t1.z), quad_from<1>(t1.w));
-    out[2] = make_uint4(quad_from<2>(t2.x), quad_from<2>(t2.y), quad_from<2>(t2.z), quad_from<2>(t2.w));
-    out[3] = make_uint4(quad_from<3>(t3.x), quad_from<3>(t3.y), quad_from<3>(t3.z), quad_from<3>(t3.w));
-}
 __global__ void __launch_bounds__(RDX_BLOCK)
 k_probe_gather_quad(const uint4* __restrict__ table, uint32_t nRecords, uint32_t nReads, uint32_t seed, uint32_t* __restrict__ sink)
 {
