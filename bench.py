@@ -511,6 +511,9 @@ def main():
         also[key] = {"workload": workload_label(key, args), "Mrays_per_s": round(r2 / dt2 / 1e6, 2), "ms_per_frame": round(1e3 * dt2 / st2, 3),
                      "dominant_kernel": kn2, "avg_launch_ms": round(1e3 * t2 / l2, 4) if l2 else None,
                      "reference_walk_equiv_GBps": round(b2 * st2 / t2 / 1e9, 1) if t2 else None,
+                     # what the REFERENCE's exhaustive walk visits for this workload's rays (SURVEY 8(d) byte model): the work a scene
+                     # asks for, whatever engine walks it -- compare workloads on it before comparing their times
+                     "reference_walk_bytes_per_frame": int(b2),
                      "note": "fabric traffic / issue counters of this workload: profiles/ (tools/gpu_profile.sh)"}
 
     if rank != 0:
