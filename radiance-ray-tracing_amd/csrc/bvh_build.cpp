@@ -31,6 +31,9 @@
 #include <map>
 #include <memory>
 #include <numeric>
+#include <atomic>
+#include <cstdlib>
+#include <thread>
 
 namespace rdx {
 namespace {
@@ -58,15 +61,106 @@ struct Node {
     bool leaf = false;
 };
 
+// ---- candidate evaluation by bins ---------------------------------------------------------------------------------------
+// The candidate planes of one axis are a short increasing sequence t_0 < t_1 < ... (at most 1024 / (depth + 1) of them).  A
+// primitive with centroid c is on the left of candidate k iff c < t_k, i.e. iff k >= b(c), b(c) = index of the first candidate
+// greater than c (K if there is none): one pass drops every primitive into bin b(c) -- a count and a box per bin -- and the
+// left / right sets of candidate k are the bins <= k / > k.  O(n + K) per axis instead of a sort; min / max do not depend on
+// the order of evaluation except for the sign of a zero, which no `cost < minCost` decision can see.  The same bins are what
+// the GPU fills for large nodes (GpuBinner below).
+struct Bins {
+    std::vector<uint32_t> cnt;      // [K + 1]
+    std::vector<Box> box;           // [K + 1]
+    std::vector<float> t;           // [K] candidate planes
+    void reset(size_t K) { cnt.assign(K + 1, 0u); box.assign(K + 1, Box{kBig, kSmall}); }
+};
+
+// index of the first candidate greater than c (t increasing, step > 0): an estimate from the spacing, corrected by comparison
+inline uint32_t bin_of(const std::vector<float>& t, float start, float invStep, float c)
+{
+    const size_t K = t.size();
+    float e = (c - start) * invStep - 1.0f;           // t_k ~ start + (k + 1) step
+    size_t b = e <= 0.0f ? 0 : (e >= (float)K ? K : (size_t)e);
+    while (b < K && !(c < t[b])) ++b;
+    while (b > 0 && c < t[b - 1]) --b;
+    return (uint32_t)b;
+}
+
+struct SplitChoice { float minCost; float bestSplit = FLT_MAX; int bestAxis = -1; };
+
+// candidates of one axis + the sweep over filled bins (bvh.cpp:116-205); false = the reference would loop forever
+inline bool make_candidates(float start, float stop, int depth, std::vector<float>& t, float& step, std::string& err)
+{
+    t.clear();
+    step = (float)((double)(stop - start) / (1024. / (depth + 1.)));
+    for (float testSplit = start + step; testSplit < stop - step; testSplit += step) {
+        t.push_back(testSplit);
+        if (testSplit + step == testSplit) {
+            err = "BVH build: split step underflows at this coordinate magnitude "
+                  "(the reference builder would loop forever here)";
+            return false;
+        }
+    }
+    return true;
+}
+inline void sweep_bins(const Bins& B, size_t n, int axis, std::vector<Box>& suf, SplitChoice& best)
+{
+    const size_t K = B.t.size();
+    if (K == 0) return;
+    suf.resize(K + 2);
+    Box acc{kBig, kSmall};
+    suf[K + 1] = acc;
+    for (size_t b = K + 1; b-- > 0;) { acc.lo = vmin(acc.lo, B.box[b].lo); acc.hi = vmax(acc.hi, B.box[b].hi); suf[b] = acc; }
+    Box pre{kBig, kSmall};
+    size_t cnt = 0;
+    for (size_t k = 0; k < K; ++k) {
+        pre.lo = vmin(pre.lo, B.box[k].lo); pre.hi = vmax(pre.hi, B.box[k].hi);
+        cnt += B.cnt[k];
+        const int countLeft = (int)cnt, countRight = (int)(n - cnt);
+        if (!(countLeft <= 1 || countRight <= 1)) {
+            float surfaceLeft = half_area(pre);
+            float surfaceRight = half_area(suf[k + 1]);
+            float totalCost = surfaceLeft * countLeft + surfaceRight * countRight;
+            if (totalCost < best.minCost) { best.minCost = totalCost; best.bestSplit = B.t[k]; best.bestAxis = axis; }
+        }
+    }
+}
+
+} // namespace
+
+// ---- GPU-assisted candidate evaluation (bvh.cpp:90-205) -------------------------------------------------------------------
+// The binning pass of a large node on the GPU (csrc/kernels.hip k_bvh_bin): the primitives of the BLAS are uploaded once, a
+// node sends its work list and its candidate planes and gets the filled bins back; the sweep, the choice and the stable
+// partition stay on the host.  Installed by the runtime when a device is up (rdx_runtime.cpp); absent, the host bins.
+static GpuBinner* g_gpuBinner = nullptr;
+static size_t g_gpuMin = 32768;
+void set_gpu_binner(GpuBinner* b, size_t minPrims) { g_gpuBinner = b; g_gpuMin = minPrims ? minPrims : 32768; }
+
+namespace {
+
+// subtrees of one BLAS are built concurrently: a bounded number of helper threads over the whole process
+std::atomic<int> g_helpers{0};
+int g_helperLimit = -1;
+inline int helper_limit()
+{
+    if (g_helperLimit < 0) {
+        const char* e = std::getenv("RDX_BUILD_THREADS");
+        const unsigned hw = std::thread::hardware_concurrency();
+        g_helperLimit = e ? std::max(0, std::atoi(e) - 1) : (int)std::min(31u, hw > 1 ? hw - 1 : 0u);
+    }
+    return g_helperLimit;
+}
+
 struct Builder {
     const std::vector<Prim>& P;
     std::string& err;
+    uint64_t gpuHandle;             // the BLAS's primitives on the GPU (0 = none)
     // scratch reused across nodes
-    std::vector<uint32_t> order;
-    std::vector<float> keys;
-    std::vector<Box> pre, suf;
+    Bins bins;
+    std::vector<Box> suf;
+    std::vector<float> gpuOut;
 
-    Builder(const std::vector<Prim>& p, std::string& e) : P(p), err(e) {}
+    Builder(const std::vector<Prim>& p, std::string& e, uint64_t gh) : P(p), err(e), gpuHandle(gh) {}
 
     std::unique_ptr<Node> make_leaf(const std::vector<uint32_t>& work)
     {
@@ -85,55 +179,53 @@ struct Builder {
         V3 bottom = kBig, top = kSmall;
         for (uint32_t w : work) { bottom = vmin(bottom, P[w].lo); top = vmax(top, P[w].hi); }
         float side1 = top.x - bottom.x, side2 = top.y - bottom.y, side3 = top.z - bottom.z;
-        float minCost = (float)n * (side1 * side2 + side2 * side3 + side3 * side1);
-        float bestSplit = FLT_MAX;
-        int bestAxis = -1;
+        SplitChoice best;
+        best.minCost = (float)n * (side1 * side2 + side2 * side3 + side3 * side1);
 
-        order.resize(n); keys.resize(n); pre.resize(n + 1); suf.resize(n + 1);
+        // candidate planes of the three axes
+        std::vector<float> cand[3];
+        float steps[3] = {0.f, 0.f, 0.f};
+        bool axisOn[3] = {false, false, false};
         for (int axis = 0; axis < 3; ++axis) {
             const float start = comp(bottom, axis), stop = comp(top, axis);
             if ((double)fabsf(stop - start) < 1e-4) continue;
-            const float step = (float)((double)(stop - start) / (1024. / (depth + 1.)));
-
-            // sort positions by centroid along this axis; prefix/suffix boxes in that order
-            std::iota(order.begin(), order.end(), 0u);
-            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-                return comp(P[work[a]].c, axis) < comp(P[work[b]].c, axis);
-            });
-            Box acc{kBig, kSmall};
-            pre[0] = acc;
-            for (size_t i = 0; i < n; ++i) {
-                const Prim& p = P[work[order[i]]];
-                keys[i] = comp(p.c, axis);
-                acc.lo = vmin(acc.lo, p.lo); acc.hi = vmax(acc.hi, p.hi);
-                pre[i + 1] = acc;
-            }
-            acc = Box{kBig, kSmall};
-            suf[n] = acc;
-            for (size_t i = n; i-- > 0;) {
-                const Prim& p = P[work[order[i]]];
-                acc.lo = vmin(acc.lo, p.lo); acc.hi = vmax(acc.hi, p.hi);
-                suf[i] = acc;
-            }
-
-            size_t cnt = 0;   // number of keys < testSplit (testSplit only grows)
-            for (float testSplit = start + step; testSplit < stop - step; testSplit += step) {
-                while (cnt < n && keys[cnt] < testSplit) ++cnt;
-                const int countLeft = (int)cnt, countRight = (int)(n - cnt);
-                if (!(countLeft <= 1 || countRight <= 1)) {
-                    float surfaceLeft = half_area(pre[cnt]);
-                    float surfaceRight = half_area(suf[cnt]);
-                    float totalCost = surfaceLeft * countLeft + surfaceRight * countRight;
-                    if (totalCost < minCost) { minCost = totalCost; bestSplit = testSplit; bestAxis = axis; }
-                }
-                if (testSplit + step == testSplit) {
-                    err = "BVH build: split step underflows at this coordinate magnitude "
-                          "(the reference builder would loop forever here)";
-                    return nullptr;
-                }
-            }
+            if (!make_candidates(start, stop, depth, cand[axis], steps[axis], err)) return nullptr;
+            axisOn[axis] = true;
         }
-
+        bool onGpu = false;
+        if (gpuHandle && g_gpuBinner && n >= g_gpuMin) {
+            // layout of the answer: per axis [K + 1] counts, then [K + 1] x {lo.xyz, hi.xyz}
+            onGpu = g_gpuBinner->bin(gpuHandle, work.data(), n, cand, gpuOut);
+        }
+        size_t off = 0;
+        for (int axis = 0; axis < 3; ++axis) {
+            if (!axisOn[axis]) continue;
+            const size_t K = cand[axis].size();
+            bins.t.swap(cand[axis]);
+            if (onGpu) {
+                bins.cnt.resize(K + 1); bins.box.resize(K + 1);
+                const float* o = gpuOut.data() + off;
+                for (size_t b = 0; b <= K; ++b) {
+                    uint32_t c; std::memcpy(&c, o + b, 4); bins.cnt[b] = c;
+                    const float* q = o + (K + 1) + 6 * b;
+                    bins.box[b] = Box{V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}};
+                }
+                off += 7 * (K + 1);
+            } else if (K) {
+                bins.reset(K);
+                const float start = comp(bottom, axis), invStep = 1.0f / steps[axis];
+                for (uint32_t w : work) {
+                    const Prim& p = P[w];
+                    const uint32_t b = bin_of(bins.t, start, invStep, comp(p.c, axis));
+                    bins.cnt[b]++;
+                    Box& bx = bins.box[b];
+                    bx.lo = vmin(bx.lo, p.lo); bx.hi = vmax(bx.hi, p.hi);
+                }
+            }
+            sweep_bins(bins, n, axis, suf, best);
+        }
+        const int bestAxis = best.bestAxis;
+        const float bestSplit = best.bestSplit;
         if (bestAxis == -1) return make_leaf(work);
 
         // stable partition + child boxes, in the reference's sequential order (exact zero signs)
@@ -146,11 +238,29 @@ struct Builder {
             else { right.push_back(w); rb.lo = vmin(rb.lo, p.lo); rb.hi = vmax(rb.hi, p.hi); }
         }
         auto inner = std::make_unique<Node>();
+        // the two subtrees are independent: the right one goes to a helper thread when one is free and it is worth a thread
+        std::unique_ptr<Node> rightNode;
+        std::string rightErr;
+        std::thread helper;
+        bool spawned = false;
+        if (right.size() >= 8192 && left.size() >= 8192 && g_helpers.fetch_add(1) < helper_limit()) {
+            spawned = true;
+            helper = std::thread([&]() {
+                Builder B2(P, rightErr, gpuHandle);
+                rightNode = B2.recurse(right, depth + 1);
+            });
+        } else if (right.size() >= 8192 && left.size() >= 8192) g_helpers.fetch_sub(1);
         inner->left = recurse(left, depth + 1);
-        if (!inner->left) return nullptr;
+        if (spawned) {
+            helper.join();
+            g_helpers.fetch_sub(1);
+            if (!rightNode && err.empty()) err = rightErr;
+        } else if (inner->left) {
+            rightNode = recurse(right, depth + 1);
+        }
+        if (!inner->left || !rightNode) return nullptr;
         inner->left->lo = lb.lo; inner->left->hi = lb.hi;
-        inner->right = recurse(right, depth + 1);
-        if (!inner->right) return nullptr;
+        inner->right = std::move(rightNode);
         inner->right->lo = rb.lo; inner->right->hi = rb.hi;
         return inner;
     }
@@ -206,8 +316,20 @@ Blas* build_blas(const float* v, uint32_t nverts, const uint32_t* idx, uint32_t 
     }
     std::vector<uint32_t> work(ntris);
     std::iota(work.begin(), work.end(), 0u);
-    Builder B(prims, err);
+    // large meshes: the primitives go to the GPU once, large nodes are binned there (GpuBinner)
+    uint64_t gpuHandle = 0;
+    if (g_gpuBinner && ntris >= g_gpuMin) {
+        std::vector<float> flat((size_t)ntris * 9u);
+        for (uint32_t j = 0; j < ntris; ++j) {
+            const Prim& q = prims[j];
+            float* f = flat.data() + 9u * j;
+            f[0] = q.lo.x; f[1] = q.lo.y; f[2] = q.lo.z; f[3] = q.hi.x; f[4] = q.hi.y; f[5] = q.hi.z; f[6] = q.c.x; f[7] = q.c.y; f[8] = q.c.z;
+        }
+        gpuHandle = g_gpuBinner->upload(flat.data(), ntris);
+    }
+    Builder B(prims, err, gpuHandle);
     std::unique_ptr<Node> root = B.recurse(work, 0);
+    if (gpuHandle) g_gpuBinner->release(gpuHandle);
     if (!root) return nullptr;
     root->lo = bottom; root->hi = top;
 
@@ -273,7 +395,7 @@ bool build_tlas(const InstanceDesc* inst, uint32_t ninst, std::vector<uint8_t>& 
     }
     std::vector<uint32_t> work(ninst);
     std::iota(work.begin(), work.end(), 0u);
-    Builder B(prims, err);
+    Builder B(prims, err, 0);
     std::unique_ptr<Node> root = B.recurse(work, 0);
     if (!root) return false;
     root->lo = bottom; root->hi = top;

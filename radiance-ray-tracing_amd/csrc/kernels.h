@@ -140,6 +140,8 @@ void launch_accumulate(hipStream_t st, const PathStreams& ps, const uint32_t* ow
                        float* imageScratch, uint8_t* image);
 void launch_finalize_all(hipStream_t st, const PathStreams& ps, uint32_t n, uint32_t nPixels, uint32_t sampleBase);
 
+// GPU-assisted BVH build (bvh_build.cpp GpuBinner): bins of one node; out = 3 axes x 7 x 1025 words (kernels.hip k_bvh_bin)
+void launch_bvh_bin(hipStream_t st, const float* prims9, const uint32_t* work, uint32_t n, const float* cand, const uint32_t K[3], uint32_t* out);
 void launch_pack_tiles(hipStream_t st, const uint8_t* image, uint8_t* packed, uint32_t w, uint32_t h, uint32_t elem,
                        uint32_t tileW, uint32_t tileH, uint32_t rank, uint32_t world, bool unpack);
 

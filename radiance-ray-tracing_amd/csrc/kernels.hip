@@ -1619,6 +1619,65 @@ k_probe_gather(const uint4* __restrict__ table, uint32_t nRecords, uint32_t nRea
     for (int k = 1; k < QUADS; ++k) { const uint4 v = p[k]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[0] = i;      // (keeps the loads alive; the table holds other values)
 }
+// ---------------------------------------------------------------------------------------------
+// GPU-assisted BVH build: the binning pass of one node (bvh_build.cpp "candidate evaluation by bins", GpuBinner)
+// ---------------------------------------------------------------------------------------------
+// prims9: the BLAS's primitives, 9 floats each (box min, box max, centroid); work[n]: the node's primitives; cand[axis * 1024 +
+// k], K[axis]: candidate planes.  Bin of a primitive = index of the first candidate greater than its centroid.  Per axis the
+// output holds BVH_BIN_SLOTS counts, then 3 x BVH_BIN_SLOTS order-preserving keys of the box minima (x, y, z), then the maxima.
+// blockIdx.y = axis; a block bins its slice into LDS and flushes the bins it touched with device atomics.
+constexpr uint32_t BVH_BIN_SLOTS = 1025u;
+__device__ __forceinline__ uint32_t bvh_key(float f) { const uint32_t b = __float_as_uint(f); return b ^ (((uint32_t)((int32_t)b >> 31)) | 0x80000000u); }
+__global__ void __launch_bounds__(256)
+k_bvh_bin_init(uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= 3u * 7u * BVH_BIN_SLOTS) return;
+    const uint32_t seg = (i % (7u * BVH_BIN_SLOTS)) / BVH_BIN_SLOTS;      // 0 count, 1-3 minima, 4-6 maxima
+    out[i] = (seg >= 1u && seg <= 3u) ? 0xffffffffu : 0u;
+}
+__global__ void __launch_bounds__(256)
+k_bvh_bin(const float* __restrict__ prims9, const uint32_t* __restrict__ work, uint32_t n, const float* __restrict__ cand,
+          uint3 K3, uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s_bin[7u * BVH_BIN_SLOTS];
+    const uint32_t axis = blockIdx.y;
+    const uint32_t K = axis == 0 ? K3.x : (axis == 1 ? K3.y : K3.z);
+    if (K == 0u) return;
+    for (uint32_t i = threadIdx.x; i < 7u * (K + 1u); i += 256u) {
+        const uint32_t seg = i / (K + 1u);
+        s_bin[seg * BVH_BIN_SLOTS + (i - seg * (K + 1u))] = (seg >= 1u && seg <= 3u) ? 0xffffffffu : 0u;
+    }
+    __syncthreads();
+    const float* t = cand + axis * 1024u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float* q = prims9 + 9u * (size_t)work[i];
+        const float c = q[6u + axis];
+        uint32_t lo = 0u, hi = K;                  // first k with c < t[k]
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (c < t[mid]) hi = mid; else lo = mid + 1u; }
+        atomicAdd(&s_bin[lo], 1u);
+        atomicMin(&s_bin[1u * BVH_BIN_SLOTS + lo], bvh_key(q[0])); atomicMin(&s_bin[2u * BVH_BIN_SLOTS + lo], bvh_key(q[1]));
+        atomicMin(&s_bin[3u * BVH_BIN_SLOTS + lo], bvh_key(q[2]));
+        atomicMax(&s_bin[4u * BVH_BIN_SLOTS + lo], bvh_key(q[3])); atomicMax(&s_bin[5u * BVH_BIN_SLOTS + lo], bvh_key(q[4]));
+        atomicMax(&s_bin[6u * BVH_BIN_SLOTS + lo], bvh_key(q[5]));
+    }
+    __syncthreads();
+    uint32_t* o = out + axis * 7u * BVH_BIN_SLOTS;
+    for (uint32_t b = threadIdx.x; b <= K; b += 256u) {
+        const uint32_t c = s_bin[b];
+        if (c == 0u) continue;
+        atomicAdd(&o[b], c);
+        for (uint32_t k = 1u; k <= 3u; ++k) atomicMin(&o[k * BVH_BIN_SLOTS + b], s_bin[k * BVH_BIN_SLOTS + b]);
+        for (uint32_t k = 4u; k <= 6u; ++k) atomicMax(&o[k * BVH_BIN_SLOTS + b], s_bin[k * BVH_BIN_SLOTS + b]);
+    }
+}
+void launch_bvh_bin(hipStream_t st, const float* prims9, const uint32_t* work, uint32_t n, const float* cand, const uint32_t K[3], uint32_t* out)
+{
+    hipLaunchKernelGGL(k_bvh_bin_init, dim3(blocks_for(3u * 7u * BVH_BIN_SLOTS, 256)), dim3(256), 0, st, out);
+    const uint32_t blocks = std::max(1u, std::min(1024u, (n + 2047u) / 2048u));
+    hipLaunchKernelGGL(k_bvh_bin, dim3(blocks, 3), dim3(256), 0, st, prims9, work, n, cand, make_uint3(K[0], K[1], K[2]), out);
+}
+
 __global__ void __launch_bounds__(RDX_BLOCK)
 k_probe_gather_quad(const uint4* __restrict__ table, uint32_t nRecords, uint32_t nReads, uint32_t seed, uint32_t* __restrict__ sink)
 {

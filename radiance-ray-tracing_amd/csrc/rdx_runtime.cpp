@@ -17,6 +17,8 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <cfloat>
 #include <string>
 #include <atomic>
 #include <thread>
@@ -167,6 +169,8 @@ struct Context {
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int groupInstances = 1;                 // pool engine: instances with bit-identical inverse matrices share one ray slot (option "group_instances")
     int userStages = 1;                     // user programs that differ from the stock one only inside stage functions run on the wavefront pipeline (option "user_stages")
+    int gpuBuild = 1;                       // BVH builder: large nodes are binned on the GPU (option "gpu_build")
+    int64_t gpuBuildMin = 32768;            // ... nodes (and meshes) of at least this many primitives (option "gpu_build_min")
     int unifiedTree = 1;                    // pool engine: large top levels of identity instances are walked by the pool (option "unified_tree")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
@@ -994,6 +998,105 @@ static void release_device_state()
     HIP_IGN(hipStreamDestroy(g.stream));
 }
 
+// GPU-assisted candidate evaluation of the BVH builder (bvh_build.h GpuBinner; reference: the candidate loop of
+// radiance/src/bvh.cpp:90-205): the primitives of a large mesh live on the device while it is built, the binning pass of its
+// large nodes is one kernel (kernels.hip k_bvh_bin).  Builder threads share one set of staging buffers behind a mutex; a call
+// is a few hundred microseconds.
+struct HipBinner final : GpuBinner {
+    std::mutex m;
+    std::map<uint64_t, float*> sets;
+    uint64_t next = 1;
+    std::atomic<uint64_t> calls{0};     // nodes binned on the device (rdx_debug_gpu_bin_calls)
+    int device = 0;
+    uint32_t* dWork = nullptr; size_t workCap = 0;
+    float* dCand = nullptr; uint32_t* dOut = nullptr; uint32_t* hOut = nullptr;
+    hipStream_t st = nullptr;
+    static constexpr size_t kSlots = 1025, kOutWords = 3 * 7 * kSlots;
+    bool ready()
+    {
+        if (st) return true;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return false; }
+        if (hipMalloc(reinterpret_cast<void**>(&dCand), 3 * 1024 * sizeof(float)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&dOut), kOutWords * 4) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&hOut), kOutWords * 4, hipHostMallocDefault) != hipSuccess) { shutdown(); return false; }
+        return true;
+    }
+    void shutdown()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        for (auto& kv : sets) HIP_IGN(hipFree(kv.second));
+        sets.clear();
+        if (dWork) HIP_IGN(hipFree(dWork));
+        if (dCand) HIP_IGN(hipFree(dCand));
+        if (dOut) HIP_IGN(hipFree(dOut));
+        if (hOut) HIP_IGN(hipHostFree(hOut));
+        if (st) HIP_IGN(hipStreamDestroy(st));
+        dWork = nullptr; workCap = 0; dCand = nullptr; dOut = nullptr; hOut = nullptr; st = nullptr;
+    }
+    uint64_t upload(const float* prims9, uint32_t n) override
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (hipSetDevice(device) != hipSuccess || !ready()) return 0;
+        float* d = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 36) != hipSuccess) return 0;
+        if (hipMemcpy(d, prims9, (size_t)n * 36, hipMemcpyHostToDevice) != hipSuccess) { HIP_IGN(hipFree(d)); return 0; }
+        sets[next] = d;
+        return next++;
+    }
+    void release(uint64_t h) override
+    {
+        std::lock_guard<std::mutex> lk(m);
+        auto it = sets.find(h);
+        if (it == sets.end()) return;
+        HIP_IGN(hipSetDevice(device));
+        HIP_IGN(hipFree(it->second));
+        sets.erase(it);
+    }
+    bool bin(uint64_t h, const uint32_t* work, size_t n, const std::vector<float> cand[3], std::vector<float>& out) override
+    {
+        std::lock_guard<std::mutex> lk(m);
+        auto it = sets.find(h);
+        if (it == sets.end() || n == 0 || n > 0xffffffffull) return false;
+        if (hipSetDevice(device) != hipSuccess || !ready()) return false;
+        uint32_t K[3];
+        for (int a = 0; a < 3; ++a) { K[a] = (uint32_t)cand[a].size(); if (K[a] > 1024u) return false; }
+        if (workCap < n) {
+            if (dWork) HIP_IGN(hipFree(dWork));
+            dWork = nullptr; workCap = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&dWork), n * 4) != hipSuccess) return false;
+            workCap = n;
+        }
+        bool ok = hipMemcpyAsync(dWork, work, n * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+        for (int a = 0; a < 3 && ok; ++a)
+            if (K[a]) ok = hipMemcpyAsync(dCand + 1024 * a, cand[a].data(), K[a] * sizeof(float), hipMemcpyHostToDevice, st) == hipSuccess;
+        if (!ok) { HIP_IGN(hipStreamSynchronize(st)); return false; }
+        launch_bvh_bin(st, it->second, dWork, (uint32_t)n, dCand, K, dOut);
+        ok = hipMemcpyAsync(hOut, dOut, kOutWords * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+        if (hipStreamSynchronize(st) != hipSuccess || !ok || hipGetLastError() != hipSuccess) return false;
+        calls.fetch_add(1);
+        out.clear();
+        for (int a = 0; a < 3; ++a) {
+            if (!K[a]) continue;
+            const uint32_t* o = hOut + (size_t)a * 7 * kSlots;
+            const size_t base = out.size(), nb = K[a] + 1u;
+            out.resize(base + 7 * nb);
+            for (size_t b = 0; b < nb; ++b) {
+                std::memcpy(&out[base + b], &o[b], 4);
+                float* q = &out[base + nb + 6 * b];
+                for (int k = 0; k < 6; ++k) {
+                    if (o[b] == 0u) { q[k] = k < 3 ? FLT_MAX : -FLT_MAX; continue; }
+                    const uint32_t key = o[(size_t)(1 + k) * kSlots + b];
+                    const uint32_t bits = (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key;
+                    std::memcpy(&q[k], &bits, 4);
+                }
+            }
+        }
+        return true;
+    }
+};
+static HipBinner g_hipBinner;
+extern "C" unsigned long long rdx_debug_gpu_bin_calls(void) { return g_hipBinner.calls.load(); }
+
 extern "C" int rdx_init(int device)
 {
     if (g0.initialized) return 0;
@@ -1006,7 +1109,10 @@ extern "C" int rdx_init(int device)
     HIP_OK(hipSetDevice(device));
     g_phys[0] = device;
     g_ndev = 1;
-    return init_device_state(device);
+    if (init_device_state(device)) return -1;
+    g_hipBinner.device = device;
+    set_gpu_binner(g0.gpuBuild ? &g_hipBinner : nullptr, (size_t)g0.gpuBuildMin);
+    return 0;
 }
 
 // Single-process multi-device rendering (SURVEY 8b "Threading", 8e): after this call every buffer lives on all `n` devices
@@ -1082,6 +1188,8 @@ extern "C" int rdx_shutdown(void)
     }
     g_ndev = 1;
     HIP_IGN(hipSetDevice(g_phys[0]));
+    set_gpu_binner(nullptr, 0);
+    g_hipBinner.shutdown();
     HIP_IGN(hipStreamSynchronize(g.stream));
     for (auto& b : g.buffers) { if (b->accel) b->accel->release(); if (b->owned && b->dptr) HIP_IGN(hipFree(b->dptr)); }
     {   // (modules created from the same text share one compiled program: user_shader.cpp's cache)
@@ -1697,6 +1805,11 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
     if (!strcmp(name, "top_flat")) { g.topFlat = value != 0; return 0; }
     if (!strcmp(name, "group_instances")) { g.groupInstances = value != 0; return 0; }
     if (!strcmp(name, "unified_tree")) { g.unifiedTree = value != 0; return 0; }
+    if (!strcmp(name, "gpu_build") || !strcmp(name, "gpu_build_min")) {
+        if (!strcmp(name, "gpu_build")) g0.gpuBuild = value != 0; else g0.gpuBuildMin = value > 0 ? value : 32768;
+        set_gpu_binner((g0.initialized && g0.gpuBuild) ? &g_hipBinner : nullptr, (size_t)g0.gpuBuildMin);
+        return 0;
+    }
     if (!strcmp(name, "user_stages")) { g.userStages = value > 2 ? 1 : (int)value; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }

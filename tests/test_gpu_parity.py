@@ -966,3 +966,31 @@ def test_user_program_traces_rays_with_the_product_library(mods):
                 assert np.array_equal(_bits(ref_h[f][h]), _bits(got[f][h])), f
         else:
             assert np.array_equal(got["hit"].astype(np.uint8), G["shadow_hit"])
+
+
+def test_gpu_assisted_builder_blobs_identical(mods):
+    """SURVEY 8(f) rank 1, second half: candidate evaluation of the BVH builder on the GPU (the binning pass of large nodes,
+    csrc/kernels.hip k_bvh_bin behind bvh_build.h GpuBinner; reference: the candidate loop of radiance/src/bvh.cpp:90-205).
+    With the threshold lowered to 64 primitives almost every inner node's candidates are evaluated on the device; the blob must
+    equal, byte for byte, the one the host path builds (which test_cpu_oracle.py holds to the reference algorithm's literal
+    restatement) -- meshes of three kinds, an instanced top level on top."""
+    rd, scenes = mods
+    plt = rd.Platform.GetPlatform()
+    s = scenes.c2_atrium(64, 36, 1, 1, detail=0.6)
+    meshes = sorted(s.meshes, key=lambda m: -len(m[1]))[:4] + [scenes.c1_cornell(64, 36, 1, 1, sphere_subdiv=4).meshes[-1]]
+    try:
+        rd.SetOption("gpu_build", 0)
+        host = [rd.BuildAccelStruct(plt, rd.Mesh(m[0], m[1])).data for m in meshes]
+        rd.SetOption("gpu_build", 1); rd.SetOption("gpu_build_min", 64)
+        import ctypes
+        from radiance_ray_tracing_amd import _lib
+        calls = _lib.lib().rdx_debug_gpu_bin_calls
+        calls.restype = ctypes.c_ulonglong
+        before = calls()
+        dev = [rd.BuildAccelStruct(plt, rd.Mesh(m[0], m[1])).data for m in meshes]
+        assert calls() - before > 300, "the device did not bin the nodes (%d calls)" % (calls() - before)
+        many = [b.data for b in rd.BuildAccelStructs(plt, [rd.Mesh(m[0], m[1]) for m in meshes])]      # builder threads share the device
+    finally:
+        rd.SetOption("gpu_build", 1); rd.SetOption("gpu_build_min", 32768)
+    for k, (a, b, c) in enumerate(zip(host, dev, many)):
+        assert len(a) > 1000 and bytes(a) == bytes(b) == bytes(c), "mesh %d (%d triangles): GPU-assisted build differs" % (k, len(meshes[k][1]))
