@@ -1,5 +1,5 @@
 /* user_stages.cl -- a user program written against the reference's shader INTERFACE (the payload / scene-data structs a raygen
- * loop and its stage functions share, samples/sbt.json's rows), with its own closest-hit shader (user_material.inc).  Own text.
+ * loop and its stage functions share, samples/sbt.json's rows), with its own closest-hit and miss shaders (user_material.inc, user_environment.inc).  Own text.
  * Run with rdx_set_option("user_stages", 2): the program's stage functions on the product's wavefront pipeline; the `raygen`
  * below is then not used (the pipeline's own generate / accumulate stages are the stock raygen loop). */
 #include "radiance.cl"
@@ -17,6 +17,9 @@ struct SceneData {
 void material(struct Payload* payload, struct HitData* hitData, struct SceneData* sceneData, image2d_array_t imageArray, sampler_t sampler)
 #include "user_material.inc"
 
+void environment(struct Payload* payload, struct SceneData* sceneData, image2d_array_t imageArray, sampler_t sampler)
+#include "user_environment.inc"
+
 void callHit(int sbtRecordOffset, struct Payload* payload, struct HitData* hitData, struct SceneData* sceneData, image2d_array_t imageArray, sampler_t sampler)
 {
     const int row = (int)hitData->instanceSBTOffset + sbtRecordOffset;
@@ -29,9 +32,8 @@ void callAnyHit(bool* cont, int sbtRecordOffset, struct Payload* payload, struct
 }
 void callMiss(int missIndex, struct Payload* payload, struct SceneData* sceneData, image2d_array_t imageArray, sampler_t sampler)
 {
-    payload->hit = false;
-    if (missIndex == 3) payload->color = (float3)(0.2f, 0.2f, 0.5f);             /* the stock sky */
-    else if (missIndex == 4) payload->color = 1.0f;
+    if (missIndex == 3) environment(payload, sceneData, imageArray, sampler);
+    else if (missIndex == 4) { payload->hit = false; payload->color = 1.0f; }    /* the shadow ray's miss */
 }
 
 __kernel void raygen(__global struct RayTraceProperties* RTProp, __global float* imageScratch, __global uchar* image,

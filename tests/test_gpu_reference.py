@@ -173,14 +173,15 @@ def test_full_size_frames_identical_to_reference(mods, ref, cfg, cull):
 def user_stage_program():
     """tests/golden/user_stages.cl with its closest-hit body spliced in (what the C preprocessor would do with the #include)"""
     text = open(os.path.join(GOLD, "user_stages.cl")).read()
-    return text.replace('#include "user_material.inc"', open(os.path.join(GOLD, "user_material.inc")).read())
+    return text.replace('#include "user_material.inc"', open(os.path.join(GOLD, "user_material.inc")).read()).replace('#include "user_environment.inc"', open(os.path.join(GOLD, "user_environment.inc")).read())
 
 
 @pytest.mark.parametrize("cfg,kw", [("c1_cornell", dict(width=480, height=270, spp=3, depth=6, sphere_subdiv=3)),
                                     ("c2_atrium", dict(width=480, height=270, spp=2, depth=8, detail=0.5))])
 def test_user_closest_hit_shader_on_the_wavefront_pipeline(mods, cfg, kw):
     """A user's own closest-hit shader (tests/golden/user_material.inc: a shadow query in the middle of the function, the
-    per-pixel RNG, next ray, throughput) runs on the wavefront pipeline -- compiled at run time, recorded / replayed around the
+    per-pixel RNG, next ray, throughput) and miss shader (user_environment.inc: a sky that depends on the ray) run on the
+    wavefront pipeline -- compiled at run time, recorded / replayed around the
     pipeline's shadow-walk stage (csrc/user_shader.cpp "stage mode") -- and the frame equals, bit for bit, the REFERENCE
     program's megakernel with that same function body in the place of its `material` (oracle/patch_material.py ->
     oracle/_ref/ref_shader_gfx950_um.co): imageScratch and RGBA8, three progressive TraceRays calls."""
@@ -201,6 +202,35 @@ def test_user_closest_hit_shader_on_the_wavefront_pipeline(mods, cfg, kw):
     st = rd.GetTraceStats()
     assert st.launches_extend >= kw["depth"] and st.launches_shadow == st.launches_extend, "the program did not run on the wavefront pipeline"
     print("%s with a user closest-hit shader: reference megakernel %.0f ms, product stage mode %.1f ms per frame" % (cfg, t[0][0], t[0][1]))
+
+
+def test_user_stage_functions_the_pipeline_cannot_serve_are_refused(mods):
+    """Stage mode serves ONE nested traceRay per closest-hit shader, and only the stock shadow query (row 2, miss 4, 0.001 / 1000):
+    a second query, or another kind of query, raises a status bit in the stage kernel and TraceRays fails naming the option that
+    runs the program as a megakernel -- no wrong frame is ever returned.  A program whose stage function uses get_global_id()
+    outside the scope of `sceneData` does not compile as a stage kernel; asserted eligibility then fails at module creation."""
+    rd, scenes = mods
+    s = scenes.c1_cornell(96, 54, spp=1, depth=3, sphere_subdiv=2)
+    base = user_stage_program()
+    twice = base.replace("const float3 tint =", "traceRay(sceneData->topLevel, 2, 4, O, L, 0.001f, 1000, &query, sceneData, imageArray, sampler);\n    const float3 tint =")
+    other = base.replace("traceRay(sceneData->topLevel, 2, 4, O, L, 0.001f, 1000, &query", "traceRay(sceneData->topLevel, 2, 4, O, L, 0.01f, 1000, &query")
+    assert twice != base and other != base
+    rd.SetShaderIncludePath("")
+    rd.SetOption("user_stages", 2)
+    try:
+        for text, what in ((twice, "more than once"), (other, "not the stock shadow query")):
+            dev = scenes.DeviceScene(s, shader_text=text)
+            with pytest.raises(rd.RadianceError, match=what):
+                rd.TraceRays(dev.plt, 0, 0, 0, 96, 54)
+        helper = base.replace("void material(", "uint my_pixel(void) { return (uint)get_global_id(0); }\nvoid material(")
+        with pytest.raises(rd.RadianceError, match="compilation failed"):
+            scenes.DeviceScene(s, shader_text=helper)
+    finally:
+        rd.SetOption("user_stages", 1)
+    # the stock pipeline is unaffected by the failed frames
+    dev2 = scenes.DeviceScene(s)
+    dev2.render()
+    assert rd.GetTraceStats().rays_primary == 96 * 54
 
 
 def test_many_instance_scene_identical_to_reference(mods, ref):

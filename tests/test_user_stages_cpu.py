@@ -24,7 +24,7 @@ def lib():
 
 def fixture_program():
     text = open(os.path.join(GOLD, "user_stages.cl")).read()
-    return text.replace('#include "user_material.inc"', open(os.path.join(GOLD, "user_material.inc")).read()).encode()
+    return text.replace('#include "user_material.inc"', open(os.path.join(GOLD, "user_material.inc")).read()).replace('#include "user_environment.inc"', open(os.path.join(GOLD, "user_environment.inc")).read()).encode()
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang is not installed")

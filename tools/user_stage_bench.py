@@ -12,7 +12,7 @@ from radiance_ray_tracing_amd import rd, scenes
 import refgpu_bind as rg
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-text = open(os.path.join(GOLD, "user_stages.cl")).read().replace('#include "user_material.inc"', open(os.path.join(GOLD, "user_material.inc")).read())
+text = open(os.path.join(GOLD, "user_stages.cl")).read().replace('#include "user_material.inc"', open(os.path.join(GOLD, "user_material.inc")).read()).replace('#include "user_environment.inc"', open(os.path.join(GOLD, "user_environment.inc")).read())
 out = {}
 for cfg in (sys.argv[1:] or ["c1_cornell", "c2_atrium"]):
     s = scenes.CONFIGS[cfg]()
