@@ -1072,6 +1072,39 @@ k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
     traverse_pool<3, INL, CULL>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
+// ---- the same three launches over quad records (traverse_pool.h QUAD; small launches: shards of a multi-GPU frame) ----------
+#ifndef POOL_WPE_QUAD
+#define POOL_WPE_QUAD 5
+#endif
+#define POOL_BOUNDS_Q __launch_bounds__(RDX_BLOCK, POOL_WPE_QUAD)
+template <bool INL>
+__global__ void POOL_BOUNDS_Q
+k_extend_pool_q(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
+{
+    ExtendPolicy pol{A, ps};
+    traverse_pool<1, INL, false, ExtendPolicy, true>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+template <bool INL>
+__global__ void POOL_BOUNDS_Q
+k_shadow_pool_q(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
+                uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
+{
+    const float* ld = sc.scene->lights[0].direction;
+    ShadowPolicy pol{A, ps, normalize3(mk3(-ld[0], -ld[1], -ld[2])), lastBounce, nPixels, sampleBase};
+    traverse_pool<2, INL, false, ShadowPolicy, true>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+template <bool INL>
+__global__ void POOL_BOUNDS_Q
+k_fused_pool_q(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
+               uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
+{
+    const float* ld = sc.scene->lights[0].direction;
+    const uint32_t m = *mPtr;
+    FusedPolicy pol{ShadowPolicy{A, psShadow, normalize3(mk3(-ld[0], -ld[1], -ld[2])), 0u, nPixels, sampleBase},
+                    ExtendPolicy{A, psExtend}, m};
+    traverse_pool<3, INL, false, FusedPolicy, true>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+
 // ---------------------------------------------------------------------------------------------
 // whole paths on the cooperative engine: one launch per chunk of samples
 // ---------------------------------------------------------------------------------------------
@@ -1425,6 +1458,14 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
             else { if (av.cull) hipLaunchKernelGGL((K<false, true>), GRID, dim3(th), lds, st, __VA_ARGS__);                 \
                    else hipLaunchKernelGGL((K<false, false>), GRID, dim3(th), lds, st, __VA_ARGS__); }                      \
         } while (0)
+#define RDX_POOL_LAUNCH_Q(K, N, ...)                                                                                           \
+        do {                                                                                                              \
+            size_t ldsq; const uint32_t thq = coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), ldsq, POOL_WPE_QUAD); \
+            const dim3 gq(coop_blocks(N, thq, ldsq, POOL_WPE_QUAD));                                                    \
+            if (av.leafRoots) hipLaunchKernelGGL((K<true>), gq, dim3(thq), ldsq, st, __VA_ARGS__);                          \
+            else hipLaunchKernelGGL((K<false>), gq, dim3(thq), ldsq, st, __VA_ARGS__);                                      \
+        } while (0)
+        if (av.quad && !av.cull) { RDX_POOL_LAUNCH_Q(k_extend_pool_q, nMax, av, ps, nPtr, counter, tmin, tmax); return; }
         RDX_POOL_LAUNCH(k_extend_pool, dim3(coop_blocks(nMax, th, lds, POOL_WPE)), av, ps, nPtr, counter, tmin, tmax);
         return;
     }
@@ -1469,6 +1510,10 @@ void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, con
     if (!nMax) return;
     if (!visit && av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
+        if (av.quad && !av.cull) {
+            RDX_POOL_LAUNCH_Q(k_shadow_pool_q, nMax, av, sc, ps, nPtr, counter, lastBounce ? 1u : 0u, nPixels, sampleBase, tmin, tmax);
+            return;
+        }
         RDX_POOL_LAUNCH(k_shadow_pool, dim3(coop_blocks(nMax, th, lds, POOL_WPE)), av, sc, ps, nPtr, counter, lastBounce ? 1u : 0u, nPixels, sampleBase,
                         tmin, tmax);
         return;
@@ -1502,6 +1547,10 @@ void launch_fused(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
     if (!mMax) return;
     if (av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
+        if (av.quad && !av.cull) {
+            RDX_POOL_LAUNCH_Q(k_fused_pool_q, 2u * mMax, av, sc, psShadow, psExtend, mPtr, counter, nPixels, sampleBase, tmin, tmax);
+            return;
+        }
         RDX_POOL_LAUNCH(k_fused_pool, dim3(coop_blocks(2u * mMax, th, lds, POOL_WPE)), av, sc, psShadow, psExtend, mPtr, counter, nPixels, sampleBase, tmin, tmax);
         return;
     }

@@ -27,6 +27,9 @@
 #ifndef RDX_SBT_HEADER
 #define RDX_SBT_HEADER "sbt_generated.h"      // tools/genSBT.py output (the table this library's stage kernels were built for)
 #endif
+#ifndef RDX_QUAD_AUTO_MAX_PATHS
+#define RDX_QUAD_AUTO_MAX_PATHS (3u << 20)      // option "quad" -1: chunks of at most this many paths walk the quad records (1/4 of a 1080p x 4 spp frame: 2.1 M)
+#endif
 #ifndef RDX_STOCK_REDUCED_HASH
 #define RDX_STOCK_REDUCED_HASH 0xf95635133b09cb3full         // of samples/shader.cl; tools/stock_shader_hash.py prints it
 #endif
@@ -71,6 +74,8 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
     uint32_t groupCount = 0;
     bool groupIdentity = false;        // ... and the group's transform is the identity: root tests in the flat top-level step
     uint32_t unifiedRoot = 0, unifiedNeed = 0;   // pool engine: one tree over top level + instances + BLASes (derive_accel), 0 = not built
+    DQuad* quad = nullptr;                 // pool engine, exhaustive walk: quad records (rdx_types.h), index = DWide index
+    uint32_t quadNeed = 0, quadUnifiedNeed = 0;  // pool-stack need of the quad walk inside one BLAS / from the unified root
     void release()
     {
         if (groupBits) HIP_IGN(hipFree(groupBits));
@@ -81,6 +86,8 @@ struct AccelCache {                // derived traversal layout of one TLAS buffe
         if (bnodes) HIP_IGN(hipFree(bnodes));
         if (tris) HIP_IGN(hipFree(tris));
         if (wide) HIP_IGN(hipFree(wide));
+        if (quad) HIP_IGN(hipFree(quad));
+        quad = nullptr;
         tnodes = nullptr; ctnodes = nullptr; insts = nullptr; bnodes = nullptr; tris = nullptr; wide = nullptr;
     }
 };
@@ -171,6 +178,8 @@ struct Context {
     int userStages = 1;                     // user programs that differ from the stock one only inside stage functions run on the wavefront pipeline (option "user_stages")
     int gpuBuild = 1;                       // BVH builder: large nodes are binned on the GPU (option "gpu_build")
     int64_t gpuBuildMin = 32768;            // ... nodes (and meshes) of at least this many primitives (option "gpu_build_min")
+    int quad = 1;                           // pool engine, exhaustive walk: quad records -- two tree levels per fetch (option "quad"): 1 on (default), 0 off,
+                                            // -1 = only for chunks the chip is not filled by (<= RDX_QUAD_AUTO_MAX_PATHS paths)
     int unifiedTree = 1;                    // pool engine: large top levels of identity instances are walked by the pool (option "unified_tree")
     int kernel = 3;                         // traversal kernel: 3 cooperative + shared node pool, 2 cooperative, 1 per-lane wide, 0 reference order
     int overlap = 0;                        // extend(d+1) || shadow(d) on two streams (experimental): 1 on, 0 off
@@ -665,6 +674,104 @@ int derive_accel(rdx_buffer_s* tb)
             unifiedNeed = uH[0] + 2u;
         }
     }
+    // Quad records (rdx_types.h DQuad): one per wide record, built from the finished wide array -- BLAS nodes and the unified
+    // tree's records alike.  need[i] = entries the LIFO pool grows by while the subtree of a popped record i is walked alone
+    // (tight mode of the pool step): the inner entries are pushed together and popped first-entry-first, so
+    // need = max(k, max_j(entries below j + need[target j])); the halves and the entries inside a half are ordered to
+    // minimise it (the visiting order is free in the exhaustive walk).
+    std::vector<DQuad> dQ(dW.size());
+    std::vector<uint32_t> qneed(dW.size(), 0);
+    {
+        struct QE { float mn[3], mx[3]; uint32_t d0, d1; };
+        auto empty = [](QE& e) { for (int k = 0; k < 3; ++k) { e.mn[k] = 0.f; e.mx[k] = 0.f; } e.d0 = 0u; e.d1 = WIDE_LEAF; };
+        auto entry_of = [](const DWide& w, int side, QE& e) {
+            for (int k = 0; k < 3; ++k) { e.mn[k] = side ? w.rmin[k] : w.lmin[k]; e.mx[k] = side ? w.rmax[k] : w.lmax[k]; }
+            const uint32_t d0 = side ? w.rd0 : w.ld0, d1 = side ? w.rd1 : w.ld1;
+            if (d1 & WIDE_LEAF) { e.d0 = wide_slot(d0); e.d1 = WIDE_LEAF | (wide_count(d1) << 24); }
+            else { e.d0 = d0; e.d1 = 0u; }
+        };
+        // the half for child `side` of wide record N
+        auto half_of = [&](const DWide& N, int side, QE out[2]) {
+            QE c;
+            entry_of(N, side, c);
+            bool pair = false;
+            if (!(c.d1 & WIDE_LEAF) && c.d0 < dW.size()) {
+                const DWide& C = dW[c.d0];
+                pair = true;
+                for (int k = 0; k < 3; ++k)
+                    if (!(std::min(C.lmin[k], C.rmin[k]) == c.mn[k] && std::max(C.lmax[k], C.rmax[k]) == c.mx[k])) pair = false;
+                // an empty entry in C (count-0 leaf with a zero box) would have entered the union above: such a record keeps its own test
+                if (pair) {
+                    entry_of(C, 0, out[0]); entry_of(C, 1, out[1]);
+                    for (int e = 0; e < 2; ++e) {
+                        out[e].d1 |= QUAD_PAIR;
+                        if (out[e].d1 & WIDE_LEAF) for (int k = 0; k < 3; ++k) { out[e].mn[k] = c.mn[k]; out[e].mx[k] = c.mx[k]; }
+                    }
+                }
+            }
+            if (!pair) { out[0] = c; empty(out[1]); }
+        };
+        // children first: explicit DFS over the records (BLAS records have larger-index children, unified records smaller ones)
+        std::vector<uint8_t> state(dW.size(), 0);       // 0 new, 1 open, 2 done
+        std::vector<uint32_t> stk;
+        for (size_t r = 0; r < dW.size(); ++r) {
+            if (state[r]) continue;
+            stk.push_back((uint32_t)r);
+            while (!stk.empty()) {
+                const uint32_t i = stk.back();
+                QE e[4];
+                half_of(dW[i], 0, e); half_of(dW[i], 1, e + 2);
+                if (state[i] == 0) {
+                    state[i] = 1;
+                    bool wait = false;
+                    for (int k = 0; k < 4; ++k)
+                        if (!(e[k].d1 & WIDE_LEAF)) {
+                            if (e[k].d0 >= dW.size()) return fail("derive_accel: wide record %u refers to record %u of %zu", i, e[k].d0, dW.size());
+                            if (state[e[k].d0] == 1) return fail("derive_accel: the wide records are not a tree (cycle through record %u)", e[k].d0);
+                            if (state[e[k].d0] == 0) { stk.push_back(e[k].d0); wait = true; }
+                        }
+                    if (wait) continue;
+                }
+                // all targets done: order the entries and store the record
+                auto nd = [&](const QE& x) -> int { return (x.d1 & WIDE_LEAF) ? -1 : (int)qneed[x.d0]; };
+                uint32_t bestNeed = ~0u; int bestArr = 0;
+                for (int arr = 0; arr < 8; ++arr) {
+                    int ord[4];
+                    const int h0 = (arr & 1) ? 2 : 0, h1 = (arr & 1) ? 0 : 2;
+                    ord[0] = h0 + ((arr >> 1) & 1); ord[1] = h0 + 1 - ((arr >> 1) & 1);
+                    ord[2] = h1 + ((arr >> 2) & 1); ord[3] = h1 + 1 - ((arr >> 2) & 1);
+                    uint32_t inner = 0, need = 0;
+                    for (int j = 3; j >= 0; --j) {          // j = pop position; `inner` = inner entries popped after j
+                        const int n = nd(e[ord[j]]);
+                        if (n < 0) continue;
+                        need = std::max(need, inner + (uint32_t)n);
+                        ++inner;
+                    }
+                    need = std::max(need, inner);
+                    if (need < bestNeed) { bestNeed = need; bestArr = arr; }
+                }
+                {
+                    const int arr = bestArr;
+                    int ord[4];
+                    const int h0 = (arr & 1) ? 2 : 0, h1 = (arr & 1) ? 0 : 2;
+                    ord[0] = h0 + ((arr >> 1) & 1); ord[1] = h0 + 1 - ((arr >> 1) & 1);
+                    ord[2] = h1 + ((arr >> 2) & 1); ord[3] = h1 + 1 - ((arr >> 2) & 1);
+                    DQuad& q = dQ[i];
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const QE& a = e[ord[2 * hh]]; const QE& b = e[ord[2 * hh + 1]];
+                        DWide& w = q.half[hh];
+                        for (int k = 0; k < 3; ++k) { w.lmin[k] = a.mn[k]; w.lmax[k] = a.mx[k]; w.rmin[k] = b.mn[k]; w.rmax[k] = b.mx[k]; }
+                        w.ld0 = a.d0; w.ld1 = a.d1; w.rd0 = b.d0; w.rd1 = b.d1;
+                    }
+                }
+                qneed[i] = bestNeed;
+                state[i] = 2;
+                stk.pop_back();
+            }
+        }
+    }
+    uint32_t maxBlasQuad = 0;
+    for (auto& kv : blasAt) if (!(kv.second.rootDesc1 & WIDE_LEAF)) maxBlasQuad = std::max(maxBlasQuad, qneed[kv.second.rootDesc0]);
     // stack need: TLAS part
     // (cooperative kernel: the instances of a top-level leaf are pushed as 16-bit masks, one entry per 16 instances,
     //  and the entry being consumed is pushed back while one of its instances is walked)
@@ -721,6 +828,7 @@ int derive_accel(rdx_buffer_s* tb)
     ac->sbtOffsets = sbtOffsets || hugeLeaf;      // (either way: the reference-order kernel, which reads the blob's own node layout)
     ac->groupCount = groupCount; ac->groupIdentity = groupIdentity;
     ac->unifiedRoot = unifiedRoot; ac->unifiedNeed = unifiedNeed;
+    ac->quadNeed = maxBlasQuad; ac->quadUnifiedNeed = unifiedRoot ? qneed[unifiedRoot] + 1u : 0u;
     ac->nWide = (uint32_t)dW.size();
     // per-lane kernels: [need][64 lanes] words of LDS per wave, 64 KB at most
     if (ac->stackNeed > 250) return fail("BVH too deep for the LDS traversal stack: %u entries per ray needed, 250 available", ac->stackNeed);
@@ -737,6 +845,7 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->bnodes, dB));
     HIP_OK(up(ac->tris, dTri));
     HIP_OK(up(ac->wide, dW));
+    HIP_OK(up(ac->quad, dQ));
     {
         const std::vector<uint32_t> gb{groupBits[0], groupBits[1], groupBits[2], groupBits[3], groupBits[4], groupBits[5], groupBits[6], groupBits[7], 0u};
         HIP_OK(up(ac->groupBits, gb));
@@ -744,17 +853,18 @@ int derive_accel(rdx_buffer_s* tb)
     // packed-word limits of the cooperative engines (kernels.h) and their LDS footprint; beyond them the per-lane wide kernel runs
     ac->coopOK = coopOK && dTri.size() <= RDX_COOP_MAX_TRI_SLOTS - 1u && dW.size() < RDX_COOP_MAX_WIDE &&
                  coop_lds_words(ac->coopNeed) <= RDX_LDS_WORDS_PER_WAVE_MAX &&
-                 pool_lds_words(std::max(ac->topNeed, ac->topFlatNeed), std::max(ac->blasNeed, ac->blasNeedAny)) <= RDX_LDS_WORDS_PER_WAVE_MAX;
+                 pool_lds_words(std::max(ac->topNeed, ac->topFlatNeed), std::max({ac->blasNeed, ac->blasNeedAny, ac->quadNeed, ac->quadUnifiedNeed})) <= RDX_LDS_WORDS_PER_WAVE_MAX;
     if (std::getenv("RDX_VERBOSE"))
-        std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u = top %u + BLAS %u)\n",
-                     nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed, ac->topNeed, ac->blasNeed);
+        std::fprintf(stderr, "[rdx] accel: %u top nodes, %u instances, %zu wide nodes, %zu triangle slots, stack need %u (cooperative kernel %u = top %u + BLAS %u; quad walk %u)\n",
+                     nTop, nInst, dW.size(), dTri.size(), ac->stackNeed, ac->coopNeed, ac->topNeed, ac->blasNeed, ac->quadNeed);
     ac->version = tb->version;
     if (acc(tb)) acc(tb)->release();
     acc(tb) = std::move(ac);
     return 0;
 }
 
-AccelView view_of(const rdx_buffer_s* tb)
+// smallChunk: the caller's launches will not fill the chip (trace_rays_device: chunks of <= RDX_QUAD_AUTO_MAX_PATHS paths)
+AccelView view_of(const rdx_buffer_s* tb, bool smallChunk = false)
 {
     AccelView v{};
     v.tnodes = acc(tb)->tnodes; v.ctnodes = acc(tb)->ctnodes; v.insts = acc(tb)->insts; v.bnodes = acc(tb)->bnodes; v.tris = acc(tb)->tris;
@@ -778,6 +888,15 @@ AccelView view_of(const rdx_buffer_s* tb)
         v.unifiedRoot = acc(tb)->unifiedRoot;
         v.topFlat = 1u; v.topNeed = 1u; v.leafRoots = 0u;
         v.blasNeed = acc(tb)->unifiedNeed;
+    }
+    // exhaustive walk of the pool engine: quad records, two tree levels per fetch (option "quad"; the culled walk keeps the
+    // wide records, whose children carry the normal cones)
+    v.quad = nullptr;
+    // (not for the unified tree: its always-entered fan-outs gain nothing from a second level per item -- 39.4 vs 35.4 ms on the
+    // 400-instance scene)
+    if (v.kernel == 3 && !v.cull && !v.unifiedRoot && (g.quad > 0 || (g.quad < 0 && smallChunk))) {
+        v.quad = acc(tb)->quad;
+        v.blasNeed = std::max(acc(tb)->quadNeed, v.blasNeed);      // (launches without a quad variant walk the wide records on the same view)
     }
     v.groupCount = (v.topFlat && !v.unifiedRoot && g.groupInstances) ? acc(tb)->groupCount : 0u;
     v.groupBits = acc(tb)->groupBits;
@@ -1810,6 +1929,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
         set_gpu_binner((g0.initialized && g0.gpuBuild) ? &g_hipBinner : nullptr, (size_t)g0.gpuBuildMin);
         return 0;
     }
+    if (!strcmp(name, "quad")) { g.quad = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "user_stages")) { g.userStages = value > 2 ? 1 : (int)value; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
@@ -1879,7 +1999,6 @@ static int trace_rays_device(uint32_t width, uint32_t height)
     SceneArgs sc;
     if (scene_args(sc)) return -1;
     if (derive_accel(bTlas)) return -1;
-    const AccelView av = view_of(bTlas);
 
     // per-frame constants live in device buffers the caller may have rewritten (sample1.cpp:480-490)
     RayTraceProperties rt; PhysicalCamera cam;
@@ -1911,6 +2030,9 @@ static int trace_rays_device(uint32_t width, uint32_t height)
     uint32_t samplesPerChunk = batch;
     if (P && (uint64_t)batch * P > (uint64_t)g.chunkPaths) samplesPerChunk = (uint32_t)std::max<int64_t>(1, g.chunkPaths / P);
     if (P && batch) { if (ensure_samples((size_t)samplesPerChunk * P)) return -1; }
+    // quad records (two tree levels per fetch, kernels at 4 waves per SIMD) for chunks whose launches do not fill the chip --
+    // shards of a multi-GPU frame, low resolutions -- where a launch lasts as long as its longest chain of dependent fetches
+    const AccelView av = view_of(bTlas, (uint64_t)samplesPerChunk * P <= (uint64_t)RDX_QUAD_AUTO_MAX_PATHS);
 
     const float tmin = 0.001f, tmax = 1000.0f;      // shader.cl:235-236, 500
     for (uint32_t s0 = 0; s0 < batch && P; s0 += samplesPerChunk) {

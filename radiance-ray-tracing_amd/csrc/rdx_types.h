@@ -99,6 +99,20 @@ struct alignas(16) DWide {        // 64 B
     float rmin[3]; uint32_t rd0;
     float rmax[3]; uint32_t rd1;
 };
-static_assert(sizeof(DWide) == 64 && sizeof(DInst) == 224, "derived layout");
+// "Quad" record of the pool engine's exhaustive walk (rdx_runtime.cpp derive_accel, traverse_pool.h): record i belongs to the
+// same inner node N as DWide record i and holds, for each of N's two children c, one HALF of two entries:
+//   * c is an inner node whose box is exactly the union of its children's boxes (always, in a tree the reference's builder
+//     made): the two children of c -- N's grandchildren -- each with its own box.  c itself is never fetched: a grandchild g's
+//     box lies inside c's, and the reference's slab decision is monotone under inclusion for rays without zero direction
+//     components, so "g's box is hit" implies "c's box is hit".  A LEAF grandchild is tested iff c's box is hit (the reference
+//     never looks at a leaf's own box), so its entry carries c's box instead of its own.  Entries of such a half have QUAD_PAIR
+//     set; rays with a (nearly) zero direction component test c's box -- a leaf entry's, or the union of the two -- as well.
+//   * otherwise (c is a leaf, or its box is not that union): c itself in the first entry -- a leaf without QUAD_PAIR is
+//     entered without a test, an inner node iff its box is hit -- and an empty second entry (leaf, count 0).
+// One 128-byte fetch thus decides two levels of the reference's tree.  Entry = {min[3], d0, max[3], d1} like a DWide child;
+// d1 = WIDE_LEAF | count << 24 | QUAD_PAIR, d0 = first triangle slot or the record index of the inner node (no cones).
+enum : uint32_t { QUAD_PAIR = 1u };
+struct alignas(16) DQuad { DWide half[2]; };
+static_assert(sizeof(DWide) == 64 && sizeof(DQuad) == 128 && sizeof(DInst) == 224, "derived layout");
 
 } // namespace rdx

@@ -223,13 +223,39 @@ __device__ __forceinline__ void pool_enqueue2(const AccelView& A, uint32_t* queu
     qTail += total;
 }
 
+// One half of a quad record (rdx_types.h DQuad) against the item's ray: entries A and B.  Inner entry: entered iff its box is
+// hit.  Leaf entry of a QUAD_PAIR half: its box is the box of the skipped inner node -- its triangles are tested iff that box
+// is hit; leaf entry otherwise: tested unconditionally, as the reference does with a leaf it pops.  Rays with a (nearly) zero
+// direction component (exactOnly: the slab decision is not monotone under box inclusion there) also test the skipped node's
+// own box -- a leaf entry's box, or the union of the two inner entries'.
+__device__ __forceinline__ void quad_half(const RayInst& Q, const float4 a0, const float4 a1, const float4 b0, const float4 b1,
+                                          uint32_t& pushA, uint32_t& pushB, uint32_t& runA, uint32_t& runB)
+{
+    // run = count << 25 | first triangle slot (WIDE_SLOT_BITS), 0 = nothing to test
+    const uint32_t ad0 = __float_as_uint(a0.w), ad1 = __float_as_uint(a1.w), bd0 = __float_as_uint(b0.w), bd1 = __float_as_uint(b1.w);
+    const bool leafA = (ad1 & WIDE_LEAF) != 0u, leafB = (bd1 & WIDE_LEAF) != 0u, pair = (ad1 & QUAD_PAIR) != 0u;
+    bool sA = slab_fast(Q, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
+    bool sB = slab_fast(Q, mk3(b0.x, b0.y, b0.z), mk3(b1.x, b1.y, b1.z));
+    if (Q.exactOnly && pair) {
+        bool u;
+        if (!leafA && !leafB)
+            u = slab_fast(Q, mk3(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z)), mk3(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z)));
+        else u = leafA ? sA : sB;                  // a leaf entry of the pair carries the skipped node's box
+        sA = sA && u; sB = sB && u;
+    }
+    if (leafA) { if (sA || !pair) runA = (wide_count(ad1) << WIDE_SLOT_BITS) | ad0; } else if (sA) pushA = ad0;
+    if (leafB) { if (sB || !pair) runB = (wide_count(bd1) << WIDE_SLOT_BITS) | bd0; } else if (sB) pushB = bd0;
+}
+
 // INL: the scene has instances whose BLAS is a single leaf of <= 8 triangles; they are handled inside the top-level step
 // (below).  A separate instantiation, chosen by the host per scene: the kernel sits at its register budget, and the extra
 // code costs scenes without such instances 10-15 % through spills even when it never runs.
 // CULL: the culled walk (kernels.hip "culled walk"): closest-hit rays skip subtrees entered beyond the best t so far and
 // push the nearer child on top; every ray skips leaves whose box it misses.  The push order then depends on the ray, so
 // A.blasNeed must be the any-order stack need (the host passes that one when the option is on).
-template <int REC, bool INL, bool CULL, class Policy>
+// QUAD: the exhaustive walk over quad records (rdx_types.h DQuad; never with CULL).  Its kernels are built for 4 waves per
+// SIMD: a record in flight is 32 registers, and they serve the launches that do not fill the chip anyway.
+template <int REC, bool INL, bool CULL, class Policy, bool QUAD = false>
 __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
                                               float tmin, float tmax, uint32_t* __restrict__ lds)
 {
@@ -776,6 +802,69 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
         // ---- pool step: up to 64 pending BLAS nodes, whichever rays they belong to -----------------------------------
         if (poolTop != 0u) {
           uint32_t rep = 0;
+          if constexpr (QUAD && !CULL) {
+            // ---- quad records (rdx_types.h DQuad): two levels of the tree per item; up to four children go back into the pool.
+            // The two halves are fetched one after the other (same 128-byte line: the second is an L1 hit): a whole record in
+            // registers costs 16 more than the kernel has.
+            do {
+                const uint32_t freeE = PCAP - poolTop;
+                const uint32_t npop = min(min(64u, poolTop), freeE >= RESERVE + 3u ? (freeE - RESERVE) / 3u : 1u);
+                COOP_STAT(6, npop);
+                const bool valid = lane < npop;
+                const uint32_t item = valid ? pool[poolTop - 1u - lane] : (lane << POOL_LANE_SHIFT);
+                poolTop -= npop;
+                const uint32_t wl = item >> POOL_LANE_SHIFT;
+                const float4* qp = reinterpret_cast<const float4*>(A.quad + (item & POOL_NODE_MASK));
+                const uint32_t slotBits = wl << POOL_LANE_SHIFT;
+                uint32_t pushA = COOP_NONE, pushB = COOP_NONE, pushC = COOP_NONE, pushE = COOP_NONE, runA = 0, runB = 0, runC = 0, runE = 0;
+                {
+                    const float4 a0 = qp[0], a1 = qp[1], b0 = qp[2], b1 = qp[3];
+                    const float4 ra = POOL_RA(rays, wl), rb = POOL_RB(rays, wl);
+                    const uint32_t qf = __float_as_uint(rb.w) >> 29;
+                    RayInst Q;
+                    Q.o = mk3(ra.x, ra.y, ra.z);
+                    Q.d = mk3(rb.x, rb.y, rb.z);
+                    Q.rcp = mk3(__builtin_amdgcn_rcpf(Q.d.x), __builtin_amdgcn_rcpf(Q.d.y), __builtin_amdgcn_rcpf(Q.d.z));
+                    Q.exactOnly = (qf & 1u) != 0u;
+                    bool live = false;
+                    if (valid) {
+                        const uint32_t hb = reinterpret_cast<const uint32_t*>(L.best)[2u * wl + 1u];     // t bits of the owner's best candidate
+                        live = !((REC != 1) && (qf & 4u) && hb != 0xffffffffu);                     // (a shadow ray already answered drops its items)
+                    }
+                    if (live) quad_half(Q, a0, a1, b0, b1, pushA, pushB, runA, runB);
+#ifdef POOL_QUAD_SEQ          // (second half fetched after the first is done: for builds that have to fit 80 registers)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    const float4 c0 = qp[4], c1 = qp[5], e0 = qp[6], e1 = qp[7];
+                    if (live) quad_half(Q, c0, c1, e0, e1, pushC, pushE, runC, runE);
+                }
+                {   // entry A ends on top: the host put the subtree with the smallest pool need there (derive_accel)
+                    const unsigned long long mE = __ballot(pushE != COOP_NONE), mC = __ballot(pushC != COOP_NONE);
+                    const unsigned long long mB = __ballot(pushB != COOP_NONE), mA = __ballot(pushA != COOP_NONE);
+                    uint32_t at = poolTop;
+                    if (pushE != COOP_NONE) pool[at + lanes_below(mE)] = slotBits | (pushE & POOL_NODE_MASK);
+                    at += (uint32_t)__popcll(mE);
+                    if (pushC != COOP_NONE) pool[at + lanes_below(mC)] = slotBits | (pushC & POOL_NODE_MASK);
+                    at += (uint32_t)__popcll(mC);
+                    if (pushB != COOP_NONE) pool[at + lanes_below(mB)] = slotBits | (pushB & POOL_NODE_MASK);
+                    at += (uint32_t)__popcll(mB);
+                    if (pushA != COOP_NONE) pool[at + lanes_below(mA)] = slotBits | (pushA & POOL_NODE_MASK);
+                    poolTop = at + (uint32_t)__popcll(mA);
+                    const int delta = (valid ? -1 : 0) + (pushA != COOP_NONE ? 1 : 0) + (pushB != COOP_NONE ? 1 : 0) + (pushC != COOP_NONE ? 1 : 0) + (pushE != COOP_NONE ? 1 : 0);
+                    if (delta != 0) atomicAdd(&pendN[wl], (uint32_t)delta);
+                }
+                while (__any((runA | runB | runC | runE) >> WIDE_SLOT_BITS)) {
+                    uint32_t ca = min(runA >> WIDE_SLOT_BITS, POOL_PIECE), cb = min(runB >> WIDE_SLOT_BITS, POOL_PIECE);
+                    pool_enqueue2(A, L.queue, rays, L.best, lane, slotBits, ca, runA & WIDE_SLOT_MASK, cb, runB & WIDE_SLOT_MASK, qHead, qTail, tmin, tmax);
+                    runA = runA - (ca << WIDE_SLOT_BITS) + ca; runB = runB - (cb << WIDE_SLOT_BITS) + cb;
+                    ca = min(runC >> WIDE_SLOT_BITS, POOL_PIECE); cb = min(runE >> WIDE_SLOT_BITS, POOL_PIECE);
+                    pool_enqueue2(A, L.queue, rays, L.best, lane, slotBits, ca, runC & WIDE_SLOT_MASK, cb, runE & WIDE_SLOT_MASK, qHead, qTail, tmin, tmax);
+                    runC = runC - (ca << WIDE_SLOT_BITS) + ca; runE = runE - (cb << WIDE_SLOT_BITS) + cb;
+                }
+                if (qTail - qHead >= POOL_TEST_MIN) POOL_TEST();
+            } while (++rep < POOL_REPEAT && poolTop >= 64u);
+            continue;
+          }
           do {
             const uint32_t freeE = PCAP - poolTop;
             const uint32_t npop = min(min(64u, poolTop), freeE > RESERVE ? freeE - RESERVE : 1u);
