@@ -1074,7 +1074,7 @@ k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
 
 // ---- the same three launches over quad records (traverse_pool.h QUAD; small launches: shards of a multi-GPU frame) ----------
 #ifndef POOL_WPE_QUAD
-#define POOL_WPE_QUAD 5
+#define POOL_WPE_QUAD 6
 #endif
 #define POOL_BOUNDS_Q __launch_bounds__(RDX_BLOCK, POOL_WPE_QUAD)
 template <bool INL>

@@ -894,9 +894,10 @@ AccelView view_of(const rdx_buffer_s* tb, bool smallChunk = false)
     v.quad = nullptr;
     // (not for the unified tree: its always-entered fan-outs gain nothing from a second level per item -- 39.4 vs 35.4 ms on the
     // 400-instance scene)
-    if (v.kernel == 3 && !v.cull && !v.unifiedRoot && (g.quad > 0 || (g.quad < 0 && smallChunk))) {
+    if (v.kernel == 3 && !v.cull && (!v.unifiedRoot || g.quad == 2) && (g.quad > 0 || (g.quad < 0 && smallChunk))) {
         v.quad = acc(tb)->quad;
-        v.blasNeed = std::max(acc(tb)->quadNeed, v.blasNeed);      // (launches without a quad variant walk the wide records on the same view)
+        // (launches without a quad variant walk the wide records on the same view)
+        v.blasNeed = std::max(v.unifiedRoot ? acc(tb)->quadUnifiedNeed : acc(tb)->quadNeed, v.blasNeed);
     }
     v.groupCount = (v.topFlat && !v.unifiedRoot && g.groupInstances) ? acc(tb)->groupCount : 0u;
     v.groupBits = acc(tb)->groupBits;
@@ -1929,7 +1930,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
         set_gpu_binner((g0.initialized && g0.gpuBuild) ? &g_hipBinner : nullptr, (size_t)g0.gpuBuildMin);
         return 0;
     }
-    if (!strcmp(name, "quad")) { g.quad = value < 0 ? -1 : (value != 0); return 0; }
+    if (!strcmp(name, "quad")) { g.quad = value < 0 ? -1 : (value > 2 ? 1 : (int)value); return 0; }      // (2: also for the unified tree -- experiment)
     if (!strcmp(name, "user_stages")) { g.userStages = value > 2 ? 1 : (int)value; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }

@@ -253,8 +253,8 @@ __device__ __forceinline__ void quad_half(const RayInst& Q, const float4 a0, con
 // CULL: the culled walk (kernels.hip "culled walk"): closest-hit rays skip subtrees entered beyond the best t so far and
 // push the nearer child on top; every ray skips leaves whose box it misses.  The push order then depends on the ray, so
 // A.blasNeed must be the any-order stack need (the host passes that one when the option is on).
-// QUAD: the exhaustive walk over quad records (rdx_types.h DQuad; never with CULL).  Its kernels are built for 4 waves per
-// SIMD: a record in flight is 32 registers, and they serve the launches that do not fill the chip anyway.
+// QUAD: the exhaustive walk over quad records (rdx_types.h DQuad; never with CULL): separate kernels (kernels.hip k_*_pool_q), so
+// that neither walk carries the other's registers.
 template <int REC, bool INL, bool CULL, class Policy, bool QUAD = false>
 __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& pol, uint32_t n, uint32_t* __restrict__ counter,
                                               float tmin, float tmax, uint32_t* __restrict__ lds)
@@ -832,7 +832,9 @@ __device__ __forceinline__ void traverse_pool(const AccelView& A, const Policy& 
                         live = !((REC != 1) && (qf & 4u) && hb != 0xffffffffu);                     // (a shadow ray already answered drops its items)
                     }
                     if (live) quad_half(Q, a0, a1, b0, b1, pushA, pushB, runA, runB);
-#ifdef POOL_QUAD_SEQ          // (second half fetched after the first is done: for builds that have to fit 80 registers)
+#ifndef POOL_QUAD_ALL_AT_ONCE // the second half is fetched after the first is done (same 128-byte line): the record then costs 16
+                              // registers, not 32, and the kernels fit 6 waves per SIMD -- all eight loads in flight at 5 waves
+                              // measured slower (25.0 vs 23.7 ms, Sponza-class)
                     __builtin_amdgcn_sched_barrier(0);
 #endif
                     const float4 c0 = qp[4], c1 = qp[5], e0 = qp[6], e1 = qp[7];
