@@ -204,7 +204,9 @@ int         rdx_set_profiling(int on);
  * beyond the best t found so far, every ray skips leaves whose box it misses -- only where a per-node normal cone proves the
  * reference's fp32 intersection test well conditioned for that ray, with margins that cover its error: the result is the
  * reference's exhaustive walk's, docs/CULLED_WALK.md has the proof; automatic = on for scenes with at least 1 M inner BVH
- * nodes, where it pays), "gpu_build" (1 (default) / 0: the BVH builder bins the candidate planes of large nodes on the GPU, DESIGN.md 7.1;
+ * nodes, where it pays), "quad" (1 (default) / 0 / -1: the exhaustive walk of the pool engine pops 128-byte quad records -- two levels of the
+ * reference's tree per item; 0 = the 64-byte records; -1 = quad records only for chunks of at most 3 M paths;
+ * results do not depend on it), "gpu_build" (1 (default) / 0: the BVH builder bins the candidate planes of large nodes on the GPU, DESIGN.md 7.1;
  * "gpu_build_min": nodes and meshes of at least this many primitives, default 32768; blobs do not depend on either),
  * "user_stages" (1 (default) = a user program that equals the stock program outside the bodies of its closest-hit / miss
  * stage functions runs those functions on the wavefront pipeline; 0 = every user program is a megakernel; 2 = the
