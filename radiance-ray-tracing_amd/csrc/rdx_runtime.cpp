@@ -679,9 +679,13 @@ int derive_accel(rdx_buffer_s* tb)
     // (tight mode of the pool step): the inner entries are pushed together and popped first-entry-first, so
     // need = max(k, max_j(entries below j + need[target j])); the halves and the entries inside a half are ordered to
     // minimise it (the visiting order is free in the exhaustive walk).
-    std::vector<DQuad> dQ(dW.size());
+    // (not built where the culled walk will run -- large scenes under the automatic rule, or option "cull" 1: the culled walk keeps
+    // the 64-byte records, and the quad records of a 10 M-triangle scene are 0.6 GB and a second of host time.  Option "cull"
+    // changed later: the exhaustive walk then uses the 64-byte records until the structure is derived again.)
+    const bool wantQuad = g0.quad != 0 && !(g0.cull > 0 || (g0.cull < 0 && dW.size() >= RDX_CULL_AUTO_MIN_WIDE)) && !unifiedRoot;
+    std::vector<DQuad> dQ(wantQuad ? dW.size() : 0);
     std::vector<uint32_t> qneed(dW.size(), 0);
-    {
+    if (wantQuad) {
         struct QE { float mn[3], mx[3]; uint32_t d0, d1; };
         auto empty = [](QE& e) { for (int k = 0; k < 3; ++k) { e.mn[k] = 0.f; e.mx[k] = 0.f; } e.d0 = 0u; e.d1 = WIDE_LEAF; };
         auto entry_of = [](const DWide& w, int side, QE& e) {
@@ -845,7 +849,7 @@ int derive_accel(rdx_buffer_s* tb)
     HIP_OK(up(ac->bnodes, dB));
     HIP_OK(up(ac->tris, dTri));
     HIP_OK(up(ac->wide, dW));
-    HIP_OK(up(ac->quad, dQ));
+    if (!dQ.empty()) HIP_OK(up(ac->quad, dQ));
     {
         const std::vector<uint32_t> gb{groupBits[0], groupBits[1], groupBits[2], groupBits[3], groupBits[4], groupBits[5], groupBits[6], groupBits[7], 0u};
         HIP_OK(up(ac->groupBits, gb));
@@ -894,10 +898,10 @@ AccelView view_of(const rdx_buffer_s* tb, bool smallChunk = false)
     v.quad = nullptr;
     // (not for the unified tree: its always-entered fan-outs gain nothing from a second level per item -- 39.4 vs 35.4 ms on the
     // 400-instance scene)
-    if (v.kernel == 3 && !v.cull && (!v.unifiedRoot || g.quad == 2) && (g.quad > 0 || (g.quad < 0 && smallChunk))) {
+    if (v.kernel == 3 && !v.cull && acc(tb)->quad && !v.unifiedRoot && (g.quad > 0 || (g.quad < 0 && smallChunk))) {
         v.quad = acc(tb)->quad;
         // (launches without a quad variant walk the wide records on the same view)
-        v.blasNeed = std::max(v.unifiedRoot ? acc(tb)->quadUnifiedNeed : acc(tb)->quadNeed, v.blasNeed);
+        v.blasNeed = std::max(acc(tb)->quadNeed, v.blasNeed);
     }
     v.groupCount = (v.topFlat && !v.unifiedRoot && g.groupInstances) ? acc(tb)->groupCount : 0u;
     v.groupBits = acc(tb)->groupBits;
@@ -1930,7 +1934,7 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
         set_gpu_binner((g0.initialized && g0.gpuBuild) ? &g_hipBinner : nullptr, (size_t)g0.gpuBuildMin);
         return 0;
     }
-    if (!strcmp(name, "quad")) { g.quad = value < 0 ? -1 : (value > 2 ? 1 : (int)value); return 0; }      // (2: also for the unified tree -- experiment)
+    if (!strcmp(name, "quad")) { g.quad = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "user_stages")) { g.userStages = value > 2 ? 1 : (int)value; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
     if (!strcmp(name, "kernel")) { if (value < 0 || value > 3) return fail("kernel must be 0, 1, 2 or 3"); g.kernel = (int)value; return 0; }
@@ -2314,7 +2318,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         c.groupsOpt = g0.groupsOpt; c.fuse = g0.fuse; c.pathMode = g0.pathMode; c.chunkPaths = g0.chunkPaths;
         c.countVisits = g0.countVisits; c.profiling = g0.profiling; c.inlineLeafRoots = g0.inlineLeafRoots; c.cull = g0.cull;
         c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap; c.groupInstances = g0.groupInstances; c.unifiedTree = g0.unifiedTree;
-        c.sortRays = g0.sortRays;
+        c.sortRays = g0.sortRays; c.quad = g0.quad;
     }
     for (int d = 0; d < n; ++d) {
         tl_ctx = g_dev[d]; tl_dev = d;
