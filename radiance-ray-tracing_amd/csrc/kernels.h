@@ -28,6 +28,7 @@ struct AccelView {                 // derived traversal layout (see rdx_types.h)
     uint32_t groupCount;           // pool engine: instances in the shared-transform group (rdx_runtime.cpp derive_accel), 0 = none
     const uint32_t* groupBits;     // ... and their slots as a bitmap of 9 words in device memory (flat top level only: <= 256 instances)
     uint32_t unifiedRoot;          // pool engine: > 0 = wide index of the super-root of the unified tree (derive_accel): rays start there
+    uint32_t quadWaves;            // ... its kernels' waves per SIMD: 6, or 7 for full-size frames (kernels.hip k_*_pool_q)
     const DQuad* quad;             // pool engine, exhaustive walk: two tree levels per record (rdx_types.h); null = walk the DWide records
 };
 

@@ -1072,20 +1072,22 @@ k_fused_pool(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExte
     traverse_pool<3, INL, CULL>(A, pol, 2u * m, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
-// ---- the same three launches over quad records (traverse_pool.h QUAD; small launches: shards of a multi-GPU frame) ----------
+// ---- the same three launches over quad records (traverse_pool.h QUAD) -------------------------------------------------------
+// W = waves per SIMD the kernel is built for: 6 (80 VGPRs), or 7 (72 VGPRs, 24-56 B of scratch) for full-size frames of scenes
+// without inline leaf roots, where the seventh wave is worth 2 % (Sponza-class 23.7 -> 23.2 ms) -- shards and scenes with leaf
+// roots lose with it (launch_*: av.quadWaves).
 #ifndef POOL_WPE_QUAD
 #define POOL_WPE_QUAD 6
 #endif
-#define POOL_BOUNDS_Q __launch_bounds__(RDX_BLOCK, POOL_WPE_QUAD)
-template <bool INL>
-__global__ void POOL_BOUNDS_Q
+template <bool INL, int W>
+__global__ void __launch_bounds__(RDX_BLOCK, W)
 k_extend_pool_q(AccelView A, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter, float tmin, float tmax)
 {
     ExtendPolicy pol{A, ps};
     traverse_pool<1, INL, false, ExtendPolicy, true>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
-template <bool INL>
-__global__ void POOL_BOUNDS_Q
+template <bool INL, int W>
+__global__ void __launch_bounds__(RDX_BLOCK, W)
 k_shadow_pool_q(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ counter,
                 uint32_t lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
@@ -1093,8 +1095,8 @@ k_shadow_pool_q(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __res
     ShadowPolicy pol{A, ps, normalize3(mk3(-ld[0], -ld[1], -ld[2])), lastBounce, nPixels, sampleBase};
     traverse_pool<2, INL, false, ShadowPolicy, true>(A, pol, *nPtr, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
-template <bool INL>
-__global__ void POOL_BOUNDS_Q
+template <bool INL, int W>
+__global__ void __launch_bounds__(RDX_BLOCK, W)
 k_fused_pool_q(AccelView A, SceneArgs sc, PathStreams psShadow, PathStreams psExtend, const uint32_t* __restrict__ mPtr,
                uint32_t* __restrict__ counter, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax)
 {
@@ -1460,10 +1462,12 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
         } while (0)
 #define RDX_POOL_LAUNCH_Q(K, N, ...)                                                                                           \
         do {                                                                                                              \
-            size_t ldsq; const uint32_t thq = coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), ldsq, POOL_WPE_QUAD); \
-            const dim3 gq(coop_blocks(N, thq, ldsq, POOL_WPE_QUAD));                                                    \
-            if (av.leafRoots) hipLaunchKernelGGL((K<true>), gq, dim3(thq), ldsq, st, __VA_ARGS__);                          \
-            else hipLaunchKernelGGL((K<false>), gq, dim3(thq), ldsq, st, __VA_ARGS__);                                      \
+            const uint32_t wq = (av.quadWaves == 7u && !av.leafRoots) ? 7u : (uint32_t)POOL_WPE_QUAD;                    \
+            size_t ldsq; const uint32_t thq = coop_threads_words(pool_words_per_wave(av.topNeed, av.blasNeed), ldsq, wq);  \
+            const dim3 gq(coop_blocks(N, thq, ldsq, wq));                                                                \
+            if (av.leafRoots) hipLaunchKernelGGL((K<true, POOL_WPE_QUAD>), gq, dim3(thq), ldsq, st, __VA_ARGS__);           \
+            else if (wq == 7u) hipLaunchKernelGGL((K<false, 7>), gq, dim3(thq), ldsq, st, __VA_ARGS__);                     \
+            else hipLaunchKernelGGL((K<false, POOL_WPE_QUAD>), gq, dim3(thq), ldsq, st, __VA_ARGS__);                       \
         } while (0)
         if (av.quad && !av.cull) { RDX_POOL_LAUNCH_Q(k_extend_pool_q, nMax, av, ps, nPtr, counter, tmin, tmax); return; }
         RDX_POOL_LAUNCH(k_extend_pool, dim3(coop_blocks(nMax, th, lds, POOL_WPE)), av, ps, nPtr, counter, tmin, tmax);

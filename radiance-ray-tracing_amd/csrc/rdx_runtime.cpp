@@ -898,8 +898,10 @@ AccelView view_of(const rdx_buffer_s* tb, bool smallChunk = false)
     v.quad = nullptr;
     // (not for the unified tree: its always-entered fan-outs gain nothing from a second level per item -- 39.4 vs 35.4 ms on the
     // 400-instance scene)
+    v.quadWaves = 6u;
     if (v.kernel == 3 && !v.cull && acc(tb)->quad && !v.unifiedRoot && (g.quad > 0 || (g.quad < 0 && smallChunk))) {
         v.quad = acc(tb)->quad;
+        v.quadWaves = (!smallChunk && pool_lds_words(v.topNeed, std::max(acc(tb)->quadNeed, v.blasNeed)) <= 1462u) ? 7u : 6u;      // (7 waves: 160 KB / 28)
         // (launches without a quad variant walk the wide records on the same view)
         v.blasNeed = std::max(acc(tb)->quadNeed, v.blasNeed);
     }
@@ -2037,7 +2039,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
     if (P && batch) { if (ensure_samples((size_t)samplesPerChunk * P)) return -1; }
     // quad records (two tree levels per fetch, kernels at 4 waves per SIMD) for chunks whose launches do not fill the chip --
     // shards of a multi-GPU frame, low resolutions -- where a launch lasts as long as its longest chain of dependent fetches
-    const AccelView av = view_of(bTlas, (uint64_t)samplesPerChunk * P <= (uint64_t)RDX_QUAD_AUTO_MAX_PATHS);
+    const AccelView av = view_of(bTlas, (uint64_t)samplesPerChunk * P <= (9ull << 19));      // (<= 4.7 M paths: the chunks that get two sample groups)
 
     const float tmin = 0.001f, tmax = 1000.0f;      // shader.cl:235-236, 500
     for (uint32_t s0 = 0; s0 < batch && P; s0 += samplesPerChunk) {
