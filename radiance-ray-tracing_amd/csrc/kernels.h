@@ -91,6 +91,8 @@ struct PathStreams {
     // per-bounce ray sort (option "sort"): the order in which the persistent traversal launch HANDS OUT the rays of this
     // bounce -- work item i is path permS[i] (shadow query) / permE[i] (next-bounce ray).  Null = identity.  Nothing is moved:
     // the streams stay in compaction order, only the waves' ray assignment follows the sort.
+    unsigned short* sortKey;     // per-bounce ray sort: the sort key of survivor j, written by the shade stage (which has the ray in
+                                 // registers) so that the sort reads 2 bytes per path instead of the 32 of its origin and direction; null = off
     const uint32_t* permS;
     const uint32_t* permE;
 };
@@ -122,7 +124,7 @@ void launch_generate(hipStream_t st, const CameraArgs& cam, const PathStreams& p
 void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, const uint32_t* nPtr, uint32_t nMax,
                    float tmin, float tmax, unsigned long long* visit, uint32_t* counter);
 void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
-                  uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase);
+                  uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase, const SortBox* sortBox = nullptr);
 void launch_shadow(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
                    uint32_t nMax, bool lastBounce, uint32_t nPixels, uint32_t sampleBase, float tmin, float tmax,
                    unsigned long long* visit, uint32_t* counter);

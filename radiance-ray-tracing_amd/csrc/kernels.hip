@@ -572,6 +572,7 @@ __device__ __forceinline__ void fill_hit_info(const AccelView& A, uint32_t instS
     h.fwd = I.fwd;
 }
 
+__device__ __forceinline__ uint32_t sort_key_of(const SortBox& B, f3 o, f3 d);      // (per-bounce ray sort, below)
 #ifndef RDX_SHADE_WAVES
 #define RDX_SHADE_WAVES 1
 #endif
@@ -580,7 +581,7 @@ __device__ __forceinline__ void fill_hit_info(const AccelView& A, uint32_t instS
 #endif
 __global__ void __launch_bounds__(RDX_SHADE_BLOCK, RDX_SHADE_WAVES)
 k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ nPtr, uint32_t* __restrict__ nOut,
-        uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
+        uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase, SortBox sortBox)
 {
     const uint32_t i = blockIdx.x * RDX_SHADE_BLOCK + threadIdx.x;
     const bool active = i < *nPtr;
@@ -644,6 +645,7 @@ k_shade(AccelView A, SceneArgs sc, PathStreams ps, const uint32_t* __restrict__ 
     ps.nThr[j] = make_float4(tn.x, tn.y, tn.z, thr.w);
     ps.colLit[j] = make_float4(lit.x, lit.y, lit.z, 0.0f);
     ps.colSh[j] = make_float4(occ.x, occ.y, occ.z, 0.0f);
+    if (ps.sortKey) ps.sortKey[j] = (unsigned short)sort_key_of(sortBox, p.nextRayOrigin, p.nextRayDirection);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -700,10 +702,16 @@ k_sort_scan_tiles(uint32_t* __restrict__ bins, uint32_t* __restrict__ sums)
 constexpr uint32_t SORT_GBINS = 1u << SORT_GBITS, SORT_GCOLS = (1u << 22) / SORT_GBINS, SORT_GTILE = 4096u;
 constexpr uint32_t SORT_GSCAN_TILES = SORT_GBINS * SORT_GCOLS / SORT_TILE;              // 1024 scan tiles of 4096 counters
 static_assert(SORT_GSCAN_TILES <= 1024u, "one thread per scan tile in k_sortg_scan_sums");
+static_assert(SORT_GBITS <= 16u, "the shade stage stores the key in 16 bits");
+__device__ __forceinline__ uint32_t sort_key_of(const SortBox& B, f3 o, f3 d)
+{
+    return ((sort_cell(B, o.x, o.y, o.z) >> (15u - SORT_GBITS)) << 3) | ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u));
+}
 __device__ __forceinline__ uint32_t sortg_key(const PathStreams& ps, const SortBox& B, uint32_t j)
 {
+    if (ps.sortKey) return ps.sortKey[j];              // written by the shade stage
     const float4 ro = ps.nRayO[j], rd = ps.nRayD[j];
-    return ((sort_cell(B, ro.x, ro.y, ro.z) >> (15u - SORT_GBITS)) << 3) | ((rd.x < 0.0f ? 1u : 0u) | (rd.y < 0.0f ? 2u : 0u) | (rd.z < 0.0f ? 4u : 0u));
+    return sort_key_of(B, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
 }
 __global__ void __launch_bounds__(256)
 k_sortg_hist(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32_t* __restrict__ H)
@@ -1486,11 +1494,14 @@ void launch_extend(hipStream_t st, const AccelView& av, const PathStreams& ps, c
 }
 
 void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, const PathStreams& ps, const uint32_t* nPtr,
-                  uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase)
+                  uint32_t* nOut, uint32_t nMax, uint32_t depth, uint32_t maxDepth, uint32_t nPixels, uint32_t sampleBase, const SortBox* sortBox)
 {
     if (!nMax) return;
-    hipLaunchKernelGGL(k_shade, dim3(blocks_for(nMax, RDX_SHADE_BLOCK)), dim3(RDX_SHADE_BLOCK), 0, st, av, sc, ps, nPtr, nOut, depth,
-                       maxDepth, nPixels, sampleBase);
+    PathStreams q = ps;
+    SortBox sb{};
+    if (sortBox) sb = *sortBox; else q.sortKey = nullptr;
+    hipLaunchKernelGGL(k_shade, dim3(blocks_for(nMax, RDX_SHADE_BLOCK)), dim3(RDX_SHADE_BLOCK), 0, st, av, sc, q, nPtr, nOut, depth,
+                       maxDepth, nPixels, sampleBase, sb);
 }
 
 void launch_ray_sort_tiles(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* H,

@@ -52,7 +52,9 @@ constexpr int RDX_MAX_DEVICES = 16;
 // / sorted): 10.4 M triangles 56.9 / 54.3 ms (the sorted hand-out makes the traversal launches 9 % faster, the eight sorts cost
 // 1.5 ms), Sponza-class 24.5 / 24.6 (break-even), sample1 13.3 / 15.4 (its rays are coherent as they come; the sort scrambles the
 // pixel order).
-constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 1u << 20;
+constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 1u << 20;      // option "sort" -1: scenes with at least this many inner BVH nodes sort their rays per bounce ...
+constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE_FULL = 1u << 15; // ... and so do scenes from this size on when the chunk fills the chip (the sort is three more dependent
+                                                           // launches per bounce: shards lose with it, and so does a scene that sits in L2 anyway)
 constexpr uint32_t RDX_CULL_AUTO_MIN_WIDE = 1u << 20;      // option "cull" -1: scenes with at least this many inner BVH nodes take the culled walk
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
@@ -143,6 +145,7 @@ struct Context {
         size_t cap = 0;
         uint32_t* sortBins = nullptr;       // per-bounce ray sort: histogram scratch (ray_sort_tiles_words()) and the permutation
         uint32_t* permE = nullptr; size_t permCap = 0;
+        unsigned short* sortKey = nullptr;  // per-bounce ray sort: keys of the survivors, written by the shade stage
         size_t stageCap = 0;                // user stage mode: paths the extra streams (shD, shHit, payC ...) hold
         uint32_t* dCounts = nullptr;        // [0] = paths generated, [d+1] = hits of bounce d, [64+d] / [128+d] ray counters
         uint32_t* hCounts = nullptr;        // pinned
@@ -1108,6 +1111,8 @@ static void release_device_state()
         if (G.hCounts) HIP_IGN(hipHostFree(G.hCounts));
         if (G.sortBins) HIP_IGN(hipFree(G.sortBins));
         if (G.permE) HIP_IGN(hipFree(G.permE));
+        if (G.sortKey) HIP_IGN(hipFree(G.sortKey));
+        G.sortKey = nullptr;
         for (int i = 0; i < 64; ++i) { HIP_IGN(hipEventDestroy(G.evShade[i])); HIP_IGN(hipEventDestroy(G.evShadow[i])); }
         HIP_IGN(hipEventDestroy(G.evDone));
         HIP_IGN(hipStreamSynchronize(G.s1)); HIP_IGN(hipStreamDestroy(G.s1));
@@ -2063,7 +2068,9 @@ static int trace_rays_device(uint32_t width, uint32_t height)
         (void)small;
         const bool overlap = g.overlap == 1 && !fuse && !visit;
         // per-bounce ray sort (north star; kernels.h): only the cooperative engines hand rays out by index
-        const bool sortOn = !visit && av.kernel >= 2 && (g.sortRays > 0 || (g.sortRays < 0 && acc(bTlas)->nWide >= RDX_SORT_AUTO_MIN_WIDE));
+        const bool sortOn = !visit && av.kernel >= 2 &&
+                            (g.sortRays > 0 || (g.sortRays < 0 && (acc(bTlas)->nWide >= RDX_SORT_AUTO_MIN_WIDE ||
+                                                                    (acc(bTlas)->nWide >= RDX_SORT_AUTO_MIN_WIDE_FULL && chunkPaths > (9ull << 19)))));
         SortBox sortBox;
         for (int k = 0; k < 3; ++k) {
             const float lo = acc(bTlas)->sceneLo[k], ext = acc(bTlas)->sceneHi[k] - lo;
@@ -2192,17 +2199,20 @@ static int trace_rays_device(uint32_t width, uint32_t height)
                 const bool last = d + 1 == maxDepth;
                 if (overlap && d > 0) HIP_OK(hipStreamWaitEvent(G.s0, G.evShadow[d - 1], 0));   // shade(d) reads col written by shadow(d-1)
                 g_timer.begin(&g.stats.ms_shade, G.s0);
-                launch_shade(G.s0, av, sc, ps, G.dCounts + d, G.dCounts + d + 1, n0, d, maxDepth, P, sampleBase);
+                if (sortOn && G.permCap < n0) {
+                    if (G.permE) HIP_IGN(hipFree(G.permE));
+                    if (G.sortKey) HIP_IGN(hipFree(G.sortKey));
+                    G.permE = nullptr; G.sortKey = nullptr; G.permCap = 0;
+                    HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.permE), (size_t)n0 * 4));
+                    HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.sortKey), (size_t)n0 * 2));
+                    G.permCap = n0;
+                }
+                ps.sortKey = sortOn ? G.sortKey : nullptr;        // (the shade stage writes the survivors' sort keys)
+                launch_shade(G.s0, av, sc, ps, G.dCounts + d, G.dCounts + d + 1, n0, d, maxDepth, P, sampleBase, sortOn ? &sortBox : nullptr);
                 g_timer.end(G.s0);
                 ps.permS = nullptr; ps.permE = nullptr;
                 if (sortOn) {
                     // per-bounce ray sort: the traversal launch below hands its rays out in (octant, Morton cell) order
-                    if (G.permCap < n0) {
-                        if (G.permE) HIP_IGN(hipFree(G.permE));
-                        G.permE = nullptr; G.permCap = 0;
-                        HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.permE), (size_t)n0 * 4));
-                        G.permCap = n0;
-                    }
                     if (!G.sortBins) HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.sortBins), (size_t)ray_sort_tiles_words() * 4));
                     g_timer.begin(&g.stats.ms_sort, G.s0);
                     launch_ray_sort_tiles(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permE);
