@@ -1766,6 +1766,20 @@ __global__ void __launch_bounds__(RDX_BLOCK) k_probe_fill(uint4* __restrict__ ta
     const uint32_t i = blockIdx.x * RDX_BLOCK + threadIdx.x;
     if (i < nQuads) table[i] = make_uint4(i, ~i, 0x5a5a5a5au, 0xa5a5a5a5u);
 }
+// which XCD does a workgroup run on?  out[b] = HW_REG_XCC_ID of block b (guide: blocks are dealt round-robin over the 8 XCDs)
+__global__ void k_probe_xcc(uint32_t* __restrict__ out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+}
+extern "C" int rdx_debug_xcc_probe(uint32_t* out, uint32_t nBlocks)
+{
+    uint32_t* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), nBlocks * 4) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_probe_xcc, dim3(nBlocks), dim3(64), 0, nullptr, d);
+    const bool ok = hipMemcpy(out, d, nBlocks * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    return ok ? 0 : -1;
+}
 // recBytes: 64 / 48 (gathers) or 16 (streaming); returns the kernel time of the last repetition in ms, < 0 on error
 extern "C" float rdx_debug_gather_probe(uint32_t recBytes, unsigned long long tableBytes, uint32_t nReads, uint32_t reps)
 {
