@@ -33,6 +33,7 @@
 #include <numeric>
 #include <atomic>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 
 namespace rdx {
@@ -243,13 +244,18 @@ struct Builder {
         std::string rightErr;
         std::thread helper;
         bool spawned = false;
-        if (right.size() >= 8192 && left.size() >= 8192 && g_helpers.fetch_add(1) < helper_limit()) {
-            spawned = true;
-            helper = std::thread([&]() {
-                Builder B2(P, rightErr, gpuHandle);
-                rightNode = B2.recurse(right, depth + 1);
-            });
-        } else if (right.size() >= 8192 && left.size() >= 8192) g_helpers.fetch_sub(1);
+        if (right.size() >= 8192 && left.size() >= 8192) {
+            if (g_helpers.fetch_add(1) < helper_limit()) {
+                try {
+                    helper = std::thread([&]() {
+                        Builder B2(P, rightErr, gpuHandle);
+                        rightNode = B2.recurse(right, depth + 1);
+                    });
+                    spawned = true;
+                } catch (const std::system_error&) { spawned = false; }      // (no thread to be had: this one does both)
+            }
+            if (!spawned) g_helpers.fetch_sub(1);
+        }
         inner->left = recurse(left, depth + 1);
         if (spawned) {
             helper.join();
