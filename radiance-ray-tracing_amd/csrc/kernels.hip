@@ -693,14 +693,17 @@ k_sort_scan_tiles(uint32_t* __restrict__ bins, uint32_t* __restrict__ sums)
 // classic three steps of a radix pass: (A) every block histograms ITS
 // tiles of 4096 consecutive paths in LDS and writes its column of the (key, block) count matrix, (B) one exclusive scan of the
 // matrix in key-major order, (C) every block reloads its scanned column into LDS and hands out positions with LDS atomics
-// while it walks its tiles again.  Two passes over the rays, 16 MB of counters, no global atomic, no memset.  (A tile-LOCAL
+// while it walks its tiles again.  Two passes over the rays, 4 MB of counters, no global atomic.  (A tile-LOCAL
 // sort -- 0.4 ms per frame -- was tried first and gains nothing: what the sort buys is that the ~400 k rays in flight on the
 // chip at any moment come from one region of the scene and meet in L2, not coherence inside a wave.)
 #ifndef SORT_GBITS
 #define SORT_GBITS 12u                 // key bits: 3 of the octant + the high SORT_GBITS - 3 bits of the 12-bit Morton cell
 #endif
-constexpr uint32_t SORT_GBINS = 1u << SORT_GBITS, SORT_GCOLS = (1u << 22) / SORT_GBINS, SORT_GTILE = 4096u;
-constexpr uint32_t SORT_GSCAN_TILES = SORT_GBINS * SORT_GCOLS / SORT_TILE;              // 1024 scan tiles of 4096 counters
+#ifndef SORT_GCOLS_LOG2
+#define SORT_GCOLS_LOG2 8u             // columns of the (key, block) count matrix = blocks of the two passes (1024 / 512 / 256 / 128: 22.38 / 22.13 / 22.06 / 22.48 ms, Sponza-class)
+#endif
+constexpr uint32_t SORT_GBINS = 1u << SORT_GBITS, SORT_GCOLS = 1u << SORT_GCOLS_LOG2, SORT_GTILE = 4096u;
+constexpr uint32_t SORT_GSCAN_TILES = SORT_GBINS * SORT_GCOLS / SORT_TILE;              // scan tiles of 4096 counters
 static_assert(SORT_GSCAN_TILES <= 1024u, "one thread per scan tile in k_sortg_scan_sums");
 static_assert(SORT_GBITS <= 16u, "the shade stage stores the key in 16 bits");
 __device__ __forceinline__ uint32_t sort_key_of(const SortBox& B, f3 o, f3 d)
