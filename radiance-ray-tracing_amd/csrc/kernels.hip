@@ -1314,6 +1314,24 @@ k_trace_batch_pool2(AccelView A, const float* __restrict__ o, const float* __res
     traverse_pool<2, INL, CULL>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
 }
 
+// (the same over quad records: the test seam walks what the frames walk)
+template <bool INL, int W>
+__global__ void __launch_bounds__(RDX_BLOCK, W)
+k_trace_batch_pool1_q(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
+                      float tmin, float tmax, rdx_hit* __restrict__ out)
+{
+    BatchPolicy pol{A, o, d, out};
+    traverse_pool<1, INL, false, BatchPolicy, true>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+template <bool INL, int W>
+__global__ void __launch_bounds__(RDX_BLOCK, W)
+k_trace_batch_pool2_q(AccelView A, const float* __restrict__ o, const float* __restrict__ d, uint32_t n, uint32_t* __restrict__ counter,
+                      float tmin, float tmax, rdx_hit* __restrict__ out)
+{
+    BatchPolicy pol{A, o, d, out};
+    traverse_pool<2, INL, false, BatchPolicy, true>(A, pol, n, counter, tmin, tmax, s_stack + (threadIdx.x >> 6) * pool_words_per_wave(A.topNeed, A.blasNeed));
+}
+
 // ---------------------------------------------------------------------------------------------
 // test seams
 // ---------------------------------------------------------------------------------------------
@@ -1621,6 +1639,11 @@ void launch_trace_batch(hipStream_t st, const AccelView& av, const float* o, con
     if (!visit && mode == 0 && av.kernel == 3) {
         size_t lds; const uint32_t th = pool_threads(av, lds);
         const dim3 gp(coop_blocks(n, th, lds, POOL_WPE));
+        if (av.quad && !av.cull) {
+            if (rec == 2) RDX_POOL_LAUNCH_Q(k_trace_batch_pool2_q, n, av, o, d, n, counter, tmin, tmax, out);
+            else RDX_POOL_LAUNCH_Q(k_trace_batch_pool1_q, n, av, o, d, n, counter, tmin, tmax, out);
+            return;
+        }
         if (rec == 2) RDX_POOL_LAUNCH(k_trace_batch_pool2, gp, av, o, d, n, counter, tmin, tmax, out);
         else RDX_POOL_LAUNCH(k_trace_batch_pool1, gp, av, o, d, n, counter, tmin, tmax, out);
         return;

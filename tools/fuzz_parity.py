@@ -3,7 +3,7 @@
 icospheres, height fields, stacks of coincident triangles that the SAH builder cannot split -> leaves of more than 8
 triangles), 1-70 instances with random affine transforms (rotation, non-uniform scale, shear, shared BLASes -> top-level
 leaves, instance masks), rays from everywhere including axis-aligned ones and rays starting on surfaces.  Every
-production kernel (3 pool, 2 per-lane stacks, 1 per-lane wide) must return the reference-order kernel's HitData exactly
+production kernel (3 pool -- culled walk, quad records, 64-byte records --, 2 per-lane stacks, 1 per-lane wide) must return the reference-order kernel's HitData exactly
 (closest hit) and its hit flag (any hit)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,16 +93,16 @@ def run(nseeds, first_seed=0, verbose=True):
         for rec in (1, 2):
             ref = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, reference_order=True)
             h = ref["hit"] == 1
-            for kernel, cull in ((3, 1), (3, 0), (2, 0), (1, 0)):
-                rd.SetOption("kernel", kernel); rd.SetOption("cull", cull)
+            for kernel, cull, quad in ((3, 1, 1), (3, 0, 1), (3, 0, 0), (2, 0, 1), (1, 0, 1)):      # (3, 0, 1): the quad-record walk
+                rd.SetOption("kernel", kernel); rd.SetOption("cull", cull); rd.SetOption("quad", quad)
                 got = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
-                rd.SetOption("kernel", 3); rd.SetOption("cull", -1)
+                rd.SetOption("kernel", 3); rd.SetOption("cull", -1); rd.SetOption("quad", 1)
                 ok = np.array_equal(ref["hit"], got["hit"])
                 if ok and rec == 1:
                     ok = all(np.array_equal(ref[f][h].view(np.uint8), got[f][h].view(np.uint8)) for f in fields)
                 if not ok:
                     bad += 1
-                    print("MISMATCH seed %d rec %d kernel %d cull %d (%d instances, %d rays, %d hits)" % (seed, rec, kernel, cull, len(s.instances), o.shape[0], int(h.sum())), flush=True)
+                    print("MISMATCH seed %d rec %d kernel %d cull %d quad %d (%d instances, %d rays, %d hits)" % (seed, rec, kernel, cull, quad, len(s.instances), o.shape[0], int(h.sum())), flush=True)
         if verbose and seed % 10 == 9:
             print("seed %d done, %d instances, %d rays, %d hits, mismatches so far %d" % (seed, len(s.instances), o.shape[0], int(h.sum()), bad), flush=True)
     return bad
