@@ -236,6 +236,11 @@ __device__ __forceinline__ void quad_half(const RayInst& Q, const float4 a0, con
     const bool leafA = (ad1 & WIDE_LEAF) != 0u, leafB = (bd1 & WIDE_LEAF) != 0u, pair = (ad1 & QUAD_PAIR) != 0u;
     bool sA = slab_fast(Q, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
     bool sB = slab_fast(Q, mk3(b0.x, b0.y, b0.z), mk3(b1.x, b1.y, b1.z));
+    // (Belt and braces.  The only box that can pass while the skipped node's box fails is one that is FLAT in the plane the ray
+    // travels in -- origin on the face, direction component exactly zero: 0 / 0 on both sides, which minnum / maxnum ignore --
+    // and every triangle under such a box is coplanar with the ray: det == 0, rejected.  With or without this block the results
+    // are the reference's (-DPOOL_EXP_NO_EXACT_UNION passes the whole suite); with it the visit set is, too.)
+#ifndef POOL_EXP_NO_EXACT_UNION
     if (Q.exactOnly && pair) {
         bool u;
         if (!leafA && !leafB)
@@ -243,6 +248,7 @@ __device__ __forceinline__ void quad_half(const RayInst& Q, const float4 a0, con
         else u = leafA ? sA : sB;                  // a leaf entry of the pair carries the skipped node's box
         sA = sA && u; sB = sB && u;
     }
+#endif
     if (leafA) { if (sA || !pair) runA = (wide_count(ad1) << WIDE_SLOT_BITS) | ad0; } else if (sA) pushA = ad0;
     if (leafB) { if (sB || !pair) runB = (wide_count(bd1) << WIDE_SLOT_BITS) | bd0; } else if (sB) pushB = bd0;
 }

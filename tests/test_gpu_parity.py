@@ -994,3 +994,61 @@ def test_gpu_assisted_builder_blobs_identical(mods):
         rd.SetOption("gpu_build", 1); rd.SetOption("gpu_build_min", 32768)
     for k, (a, b, c) in enumerate(zip(host, dev, many)):
         assert len(a) > 1000 and bytes(a) == bytes(b) == bytes(c), "mesh %d (%d triangles): GPU-assisted build differs" % (k, len(meshes[k][1]))
+
+
+def test_axis_parallel_rays_in_box_planes_match_the_reference_order_walk(mods):
+    """The quad-record walk skips a level of the reference's tree on the strength of "a grandchild's box lies inside the child's and
+    the slab decision is monotone under inclusion" -- which NaNs strain: a ray with a zero direction component whose origin lies
+    exactly in a face plane of a box (0 / 0 in the reference's division form).  Such rays take the walk's exact path (the skipped
+    node's box is tested too; traverse_pool.h quad_half explains why the results would agree even without it).  Scene: identity instances of axis-aligned boxes and grids, so that BVH boxes share planes with
+    vertices; rays: origins with one, two or three coordinates equal to vertex coordinates, directions along the axes and in the
+    coordinate planes.  Every engine must return the reference-order walk's HitData, closest hit and any hit."""
+    rd, scenes = mods
+    rng = np.random.default_rng(77)
+    s = scenes.Scene("planes")
+    s.materials = [scenes.material((0.7, 0.7, 0.7))]
+    I = np.eye(4, dtype=np.float32)
+    verts = []
+    for k in range(6):
+        lo = np.round(rng.uniform(-3, 0, 3) * 4) / 4; hi = lo + np.round(rng.uniform(0.5, 3, 3) * 4) / 4
+        m = scenes.box(lo.tolist(), hi.tolist()); s.add_instance(s.add_mesh(m), I, 0); verts.append(np.asarray(m[0], np.float32).reshape(-1, 3))
+    m = scenes.heightfield([-3, -1, -3], [0.25, 0, 0], [0, 0, 0.25], [0, 1, 0], 24, 24, 0.0, 1)       # a flat 24 x 24 grid: 1152 triangles in one plane
+    s.add_instance(s.add_mesh(m), I, 0); verts.append(np.asarray(m[0], np.float32).reshape(-1, 3))
+    m = scenes.icosphere(3, 1.0); s.add_instance(s.add_mesh(m), I, 0); verts.append(np.asarray(m[0], np.float32).reshape(-1, 3))
+    s.camera = scenes.blender_camera(64, 48, 0.05, 0.036, 9.0, 0.0, (0.5, 14.0, 1.0), (-96.0, 180.0, 0.0))
+    s.sceneProps = scenes.blender_dir_light(-45.0, 20.0, 5.0)
+    s.rtprop = scenes._rtprop(0, 1, 2)
+    V = np.concatenate(verts)
+    n = 20000
+    o = V[rng.integers(0, len(V), n)].copy()
+    keep = rng.integers(1, 8, n)                     # which coordinates stay exactly on a vertex coordinate (bit mask, >= 1)
+    for a in range(3):
+        move = (keep >> a) & 1 == 0
+        o[move, a] += rng.uniform(-4, 4, int(move.sum())).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    kind = rng.integers(0, 3, n)
+    ax = rng.integers(0, 3, n); sg = rng.choice([-1.0, 1.0], n).astype(np.float32)
+    d[np.arange(n), ax] = sg                          # along an axis
+    two = kind == 1                                   # in a coordinate plane: one component exactly zero
+    d[two] = rng.normal(size=(int(two.sum()), 3)).astype(np.float32); d[two, ax[two]] = 0.0
+    neg0 = kind == 2                                  # along an axis with the zeros signed
+    d[neg0] = d[neg0] + np.float32(-0.0)
+    d[neg0 & (rng.random(n) < 0.5)] *= np.float32(1.0)
+    nz = np.linalg.norm(d, axis=1) > 0
+    o, d = np.ascontiguousarray(o[nz]), np.ascontiguousarray(d[nz] / np.linalg.norm(d[nz], axis=1, keepdims=True))
+    dev = scenes.DeviceScene(s)
+    fields = ("distance", "primitiveIndex", "instanceIndex", "barycentric", "hitPoint")
+    try:
+        for rec in (1, 2):
+            ref = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec, reference_order=True)
+            h = ref["hit"] == 1
+            assert 0.05 < h.mean() < 0.95
+            for kernel, quad in ((3, 1), (3, 0), (2, 1), (1, 1)):
+                rd.SetOption("kernel", kernel); rd.SetOption("quad", quad)
+                got = rd.TraceBatch(dev.topAccelStruct, o, d, 0.001, 1000.0, rec)
+                assert np.array_equal(ref["hit"], got["hit"]), (rec, kernel, quad, int((ref["hit"] != got["hit"]).sum()))
+                if rec == 1:
+                    for f in fields:
+                        assert np.array_equal(ref[f][h].view(np.uint8), got[f][h].view(np.uint8)), (kernel, quad, f)
+    finally:
+        rd.SetOption("kernel", 3); rd.SetOption("quad", 1)
