@@ -195,7 +195,7 @@ int         rdx_set_profiling(int on);
  * cooperative with a shared node pool (default), 2 = wave-cooperative with per-lane node stacks, 1 = per-lane wide
  * nodes, 0 = reference order; all four give identical results, the option exists for A/B measurements and
  * cross-checks), "user_shader_local_size" (work-group size of a user shader program's launch, default 64; the reference
- * launches with 1, radiance.cpp:250-259 -- results do not depend on it), "sort" (-1 (default) = automatic: on for scenes of >= 1 M inner BVH nodes, and from 32 k inner nodes on when the chunk fills the chip (> 4.7 M paths); 1 / 0 = on / off: per-bounce ray sort -- the survivors of a bounce are handed to the
+ * launches with 1, radiance.cpp:250-259 -- results do not depend on it), "sort" (-1 (default) = automatic: on for scenes of >= 1 M inner BVH nodes, and from 32 k inner nodes on in chunks of more than 1.5 M paths; 1 / 0 = on / off: per-bounce ray sort -- the survivors of a bounce are handed to the
  * traversal launch in (Morton cell of the origin, direction octant) order, by an index permutation from a counting sort; the
  * path streams are not moved and no result depends on it), "textures" (0 (default) / 1.  The live reference shader has every texture read commented out (`uint4 tex =
  * 0.0f;//read_imageui(...)`, samples/shader.cl:379,411,421,445), so a material with a texture index renders with texel 0; that

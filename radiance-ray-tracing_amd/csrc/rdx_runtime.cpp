@@ -53,8 +53,8 @@ constexpr int RDX_MAX_DEVICES = 16;
 // 1.5 ms), Sponza-class 24.5 / 24.6 (break-even), sample1 13.3 / 15.4 (its rays are coherent as they come; the sort scrambles the
 // pixel order).
 constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE = 1u << 20;      // option "sort" -1: scenes with at least this many inner BVH nodes sort their rays per bounce ...
-constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE_FULL = 1u << 15; // ... and so do scenes from this size on when the chunk fills the chip (the sort is three more dependent
-                                                           // launches per bounce: shards lose with it, and so does a scene that sits in L2 anyway)
+constexpr uint32_t RDX_SORT_AUTO_MIN_WIDE_FULL = 1u << 15; // ... and so do scenes from this size on for chunks of more than sortMinPaths paths (the sort is four more dependent
+                                                           // launches per bounce: small shards lose with it, and so does a scene that sits in L2 anyway)
 constexpr uint32_t RDX_CULL_AUTO_MIN_WIDE = 1u << 20;      // option "cull" -1: scenes with at least this many inner BVH nodes take the culled walk
 struct AccelCache {                // derived traversal layout of one TLAS buffer
     uint64_t version = ~0ull;
@@ -179,6 +179,10 @@ struct Context {
     int topFlat = 1;                        // pool engine: evaluate small top-level trees all at once (option "top_flat")
     int groupInstances = 1;                 // pool engine: instances with bit-identical inverse matrices share one ray slot (option "group_instances")
     int userStages = 1;                     // user programs that differ from the stock one only inside stage functions run on the wavefront pipeline (option "user_stages")
+    int64_t sortMinPaths = 3ll << 19;       // chunks of more paths than this (1.5 M) sort the rays of mid-size scenes and use the 7-wave quad kernels (option
+                                            // "sort_min_paths"; 4.7 M / 3 M / 1.5 M: 1/2 frame 13.6 / 12.4 / 12.4 ms, 1/4 frame 7.57 / 7.57 / 7.35 ms, Sponza-class)
+    int64_t smallChunkPaths = 9ll << 19;    // chunks of at most this many paths (4.7 M) do not fill the chip: two sample groups, 6-wave quad kernels, no ray sort
+                                            // (option "small_chunk_paths")
     int gpuBuild = 1;                       // BVH builder: large nodes are binned on the GPU (option "gpu_build")
     int64_t gpuBuildMin = 32768;            // ... nodes (and meshes) of at least this many primitives (option "gpu_build_min")
     int quad = 1;                           // pool engine, exhaustive walk: quad records -- two tree levels per fetch (option "quad"): 1 on (default), 0 off,
@@ -1941,6 +1945,8 @@ extern "C" int rdx_set_option(const char* name, int64_t value)
         set_gpu_binner((g0.initialized && g0.gpuBuild) ? &g_hipBinner : nullptr, (size_t)g0.gpuBuildMin);
         return 0;
     }
+    if (!strcmp(name, "sort_min_paths")) { g.sortMinPaths = value > 0 ? value : (3ll << 19); return 0; }
+    if (!strcmp(name, "small_chunk_paths")) { g.smallChunkPaths = value > 0 ? value : (9ll << 19); return 0; }
     if (!strcmp(name, "quad")) { g.quad = value < 0 ? -1 : (value != 0); return 0; }
     if (!strcmp(name, "user_stages")) { g.userStages = value > 2 ? 1 : (int)value; return 0; }
     if (!strcmp(name, "inline_leaf_roots")) { g.inlineLeafRoots = value != 0; return 0; }
@@ -2044,7 +2050,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
     if (P && batch) { if (ensure_samples((size_t)samplesPerChunk * P)) return -1; }
     // quad records (two tree levels per fetch, kernels at 4 waves per SIMD) for chunks whose launches do not fill the chip --
     // shards of a multi-GPU frame, low resolutions -- where a launch lasts as long as its longest chain of dependent fetches
-    const AccelView av = view_of(bTlas, (uint64_t)samplesPerChunk * P <= (9ull << 19));      // (<= 4.7 M paths: the chunks that get two sample groups)
+    const AccelView av = view_of(bTlas, (uint64_t)samplesPerChunk * P <= (uint64_t)g.sortMinPaths);
 
     const float tmin = 0.001f, tmax = 1000.0f;      // shader.cl:235-236, 500
     for (uint32_t s0 = 0; s0 < batch && P; s0 += samplesPerChunk) {
@@ -2056,7 +2062,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
         // The chunk's samples are split into groups with their own streams and counts, each launching 1/nGroups of
         // the resident grid, so that one group's launches run inside the ramp and drain of the other's
         // (kernels.hip: set_grid_share).  Two groups: -5 % at 1/8, -3 % at 1/2 of a 1080p x 4 spp frame; four: slower.
-        const bool small = chunkPaths <= (9ull << 19) && sc_n >= 2 && av.kernel >= 2;      // <= 4.7 M paths
+        const bool small = chunkPaths <= (uint64_t)g.smallChunkPaths && sc_n >= 2 && av.kernel >= 2;
         const uint32_t wantGroups = visit ? 1u : g.groupsOpt ? (uint32_t)g.groupsOpt : small ? 2u : 1u;
         int nGroups = (int)std::min<uint32_t>(wantGroups, sc_n);
         set_grid_share((uint32_t)nGroups);
@@ -2070,7 +2076,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
         // per-bounce ray sort (north star; kernels.h): only the cooperative engines hand rays out by index
         const bool sortOn = !visit && av.kernel >= 2 &&
                             (g.sortRays > 0 || (g.sortRays < 0 && (acc(bTlas)->nWide >= RDX_SORT_AUTO_MIN_WIDE ||
-                                                                    (acc(bTlas)->nWide >= RDX_SORT_AUTO_MIN_WIDE_FULL && chunkPaths > (9ull << 19)))));
+                                                                    (acc(bTlas)->nWide >= RDX_SORT_AUTO_MIN_WIDE_FULL && chunkPaths > (uint64_t)g.sortMinPaths))));
         SortBox sortBox;
         for (int k = 0; k < 3; ++k) {
             const float lo = acc(bTlas)->sceneLo[k], ext = acc(bTlas)->sceneHi[k] - lo;
@@ -2330,7 +2336,7 @@ extern "C" int rdx_trace_rays(uint32_t, uint32_t, uint32_t, uint32_t width, uint
         c.groupsOpt = g0.groupsOpt; c.fuse = g0.fuse; c.pathMode = g0.pathMode; c.chunkPaths = g0.chunkPaths;
         c.countVisits = g0.countVisits; c.profiling = g0.profiling; c.inlineLeafRoots = g0.inlineLeafRoots; c.cull = g0.cull;
         c.textures = g0.textures; c.topFlat = g0.topFlat; c.kernel = g0.kernel; c.overlap = g0.overlap; c.groupInstances = g0.groupInstances; c.unifiedTree = g0.unifiedTree;
-        c.sortRays = g0.sortRays; c.quad = g0.quad;
+        c.sortRays = g0.sortRays; c.quad = g0.quad; c.smallChunkPaths = g0.smallChunkPaths; c.sortMinPaths = g0.sortMinPaths;
     }
     for (int d = 0; d < n; ++d) {
         tl_ctx = g_dev[d]; tl_dev = d;
