@@ -697,7 +697,7 @@ k_sort_scan_tiles(uint32_t* __restrict__ bins, uint32_t* __restrict__ sums)
 // sort -- 0.4 ms per frame -- was tried first and gains nothing: what the sort buys is that the ~400 k rays in flight on the
 // chip at any moment come from one region of the scene and meet in L2, not coherence inside a wave.)
 #ifndef SORT_GBITS
-#define SORT_GBITS 12u                 // key bits: 3 of the octant + the high SORT_GBITS - 3 bits of the 12-bit Morton cell
+#define SORT_GBITS 13u                 // key bits: 3 of the octant + the high SORT_GBITS - 3 bits of the 12-bit Morton cell (12 / 13 / 14: 22.15 / 22.10 / 22.31 ms Sponza-class, 64.1 / 63.1 / 62.6 ms on the 10.4 M-triangle scene)
 #endif
 #ifndef SORT_GCOLS_LOG2
 #define SORT_GCOLS_LOG2 8u             // columns of the (key, block) count matrix = blocks of the two passes (1024 / 512 / 256 / 128: 22.38 / 22.13 / 22.06 / 22.48 ms, Sponza-class)
