@@ -105,7 +105,7 @@ constexpr uint32_t SORT_TILE = 4096u;                // counters per scan tile
 struct SortBox { float lo[3]; float inv[3]; };      // cell = (p - lo) * inv, clamped to 0..15
 // perm: nMax words; H: ray_sort_tiles_words() words of scratch
 void launch_ray_sort_tiles(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* H,
-                           uint32_t* perm);
+                           uint32_t* perm, bool largeScene = false);
 uint32_t ray_sort_tiles_words();
 
 // LDS words one wave of the cooperative / pool engine needs for the given stack needs (traverse_coop.h, traverse_pool.h)

@@ -697,46 +697,55 @@ k_sort_scan_tiles(uint32_t* __restrict__ bins, uint32_t* __restrict__ sums)
 // sort -- 0.4 ms per frame -- was tried first and gains nothing: what the sort buys is that the ~400 k rays in flight on the
 // chip at any moment come from one region of the scene and meet in L2, not coherence inside a wave.)
 #ifndef SORT_GBITS
-#define SORT_GBITS 13u                 // key bits: 3 of the octant + the high SORT_GBITS - 3 bits of the 12-bit Morton cell (12 / 13 / 14: 22.15 / 22.10 / 22.31 ms Sponza-class, 64.1 / 63.1 / 62.6 ms on the 10.4 M-triangle scene)
+#define SORT_GBITS 13u                 // key bits: 3 of the octant + the high bits - 3 bits of the 12-bit Morton cell (12 / 13 / 14: 22.15 / 22.10 / 22.31 ms Sponza-class, 64.1 / 63.1 / 62.6 ms on the 10.4 M-triangle scene)
 #endif
 #ifndef SORT_GCOLS_LOG2
 #define SORT_GCOLS_LOG2 8u             // columns of the (key, block) count matrix = blocks of the two passes (1024 / 512 / 256 / 128: 22.38 / 22.13 / 22.06 / 22.48 ms, Sponza-class)
 #endif
-constexpr uint32_t SORT_GBINS = 1u << SORT_GBITS, SORT_GCOLS = 1u << SORT_GCOLS_LOG2, SORT_GTILE = 4096u;
-constexpr uint32_t SORT_GSCAN_TILES = SORT_GBINS * SORT_GCOLS / SORT_TILE;              // scan tiles of 4096 counters
+// The number of key bits is a launch parameter: SORT_GBITS (13) by default, SORT_GBITS_LARGE (14) for the scenes whose
+// records live in HBM (62.6 vs 63.1 ms on the 10.4 M-triangle scene; the Sponza-class scene loses with 14: 22.3 vs 22.1).
+#ifndef SORT_GBITS_LARGE
+#define SORT_GBITS_LARGE 14u
+#endif
+constexpr uint32_t SORT_GBITS_MAX = SORT_GBITS_LARGE > SORT_GBITS ? SORT_GBITS_LARGE : SORT_GBITS;
+constexpr uint32_t SORT_GBINS = 1u << SORT_GBITS_MAX, SORT_GCOLS = 1u << SORT_GCOLS_LOG2, SORT_GTILE = 4096u;
+constexpr uint32_t SORT_GSCAN_TILES = SORT_GBINS * SORT_GCOLS / SORT_TILE;              // scan tiles of 4096 counters (at most)
 static_assert(SORT_GSCAN_TILES <= 1024u, "one thread per scan tile in k_sortg_scan_sums");
-static_assert(SORT_GBITS <= 16u, "the shade stage stores the key in 16 bits");
+static_assert(SORT_GBITS_MAX <= 14u, "the histogram of a block lives in 64 KB of LDS");
+// full-resolution key, 15 bits: 12-bit Morton cell << 3 | direction octant (what the shade stage stores)
 __device__ __forceinline__ uint32_t sort_key_of(const SortBox& B, f3 o, f3 d)
 {
-    return ((sort_cell(B, o.x, o.y, o.z) >> (15u - SORT_GBITS)) << 3) | ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u));
+    return (sort_cell(B, o.x, o.y, o.z) << 3) | ((d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u));
 }
-__device__ __forceinline__ uint32_t sortg_key(const PathStreams& ps, const SortBox& B, uint32_t j)
+// ... reduced to `bits` key bits: the high bits - 3 bits of the cell, the octant
+__device__ __forceinline__ uint32_t sortg_key(const PathStreams& ps, const SortBox& B, uint32_t j, uint32_t bits)
 {
-    if (ps.sortKey) return ps.sortKey[j];              // written by the shade stage
-    const float4 ro = ps.nRayO[j], rd = ps.nRayD[j];
-    return sort_key_of(B, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z));
+    uint32_t k;
+    if (ps.sortKey) k = ps.sortKey[j];                 // written by the shade stage
+    else { const float4 ro = ps.nRayO[j], rd = ps.nRayD[j]; k = sort_key_of(B, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z)); }
+    return (((k >> 3) >> (15u - bits)) << 3) | (k & 7u);
 }
 __global__ void __launch_bounds__(256)
-k_sortg_hist(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32_t* __restrict__ H)
+k_sortg_hist(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, uint32_t* __restrict__ H, uint32_t bits)
 {
     __shared__ uint32_t cnt[SORT_GBINS];
-    const uint32_t m = *mPtr, t = threadIdx.x, cols = gridDim.x;
-    for (uint32_t k = t; k < SORT_GBINS; k += 256u) cnt[k] = 0u;
+    const uint32_t m = *mPtr, t = threadIdx.x, cols = gridDim.x, bins = 1u << bits;
+    for (uint32_t k = t; k < bins; k += 256u) cnt[k] = 0u;
     __syncthreads();
     for (uint32_t base = blockIdx.x * SORT_GTILE; base < m; base += cols * SORT_GTILE)
         for (uint32_t i = 0; i < 16u; ++i) {
             const uint32_t j = base + i * 256u + t;
-            if (j < m) atomicAdd(&cnt[sortg_key(ps, B, j)], 1u);
+            if (j < m) atomicAdd(&cnt[sortg_key(ps, B, j, bits)], 1u);
         }
     __syncthreads();
-    for (uint32_t k = t; k < SORT_GBINS; k += 256u) H[k * SORT_GCOLS + blockIdx.x] = cnt[k];       // (columns >= gridDim.x stay zero)
+    for (uint32_t k = t; k < bins; k += 256u) H[k * SORT_GCOLS + blockIdx.x] = cnt[k];       // (columns >= gridDim.x stay zero)
 }
 __global__ void __launch_bounds__(1024)
-k_sortg_scan_sums(uint32_t* __restrict__ sums)
+k_sortg_scan_sums(uint32_t* __restrict__ sums, uint32_t nTiles)
 {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
-    const uint32_t v = t < SORT_GSCAN_TILES ? sums[t] : 0u;
+    const uint32_t v = t < nTiles ? sums[t] : 0u;
     part[t] = v;
     __syncthreads();
     for (uint32_t off = 1; off < 1024u; off <<= 1) {
@@ -745,15 +754,15 @@ k_sortg_scan_sums(uint32_t* __restrict__ sums)
         part[t] += x;
         __syncthreads();
     }
-    if (t < SORT_GSCAN_TILES) sums[t] = part[t] - v;
+    if (t < nTiles) sums[t] = part[t] - v;
 }
 __global__ void __launch_bounds__(256)
 k_sortg_scatter(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, const uint32_t* __restrict__ H, const uint32_t* __restrict__ sums,
-                uint32_t* __restrict__ perm)
+                uint32_t* __restrict__ perm, uint32_t bits)
 {
     __shared__ uint32_t cnt[SORT_GBINS];
-    const uint32_t m = *mPtr, t = threadIdx.x, cols = gridDim.x;
-    for (uint32_t k = t; k < SORT_GBINS; k += 256u) {
+    const uint32_t m = *mPtr, t = threadIdx.x, cols = gridDim.x, bins = 1u << bits;
+    for (uint32_t k = t; k < bins; k += 256u) {
         const uint32_t at = k * SORT_GCOLS + blockIdx.x;
         cnt[k] = H[at] + sums[at / SORT_TILE];
     }
@@ -761,7 +770,7 @@ k_sortg_scatter(PathStreams ps, const uint32_t* __restrict__ mPtr, SortBox B, co
     for (uint32_t base = blockIdx.x * SORT_GTILE; base < m; base += cols * SORT_GTILE)
         for (uint32_t i = 0; i < 16u; ++i) {
             const uint32_t j = base + i * 256u + t;
-            if (j < m) perm[atomicAdd(&cnt[sortg_key(ps, B, j)], 1u)] = j;      // (the order inside a key is arbitrary: no result depends on it)
+            if (j < m) perm[atomicAdd(&cnt[sortg_key(ps, B, j, bits)], 1u)] = j;      // (the order inside a key is arbitrary: no result depends on it)
         }
 }
 
@@ -1526,16 +1535,17 @@ void launch_shade(hipStream_t st, const AccelView& av, const SceneArgs& sc, cons
 }
 
 void launch_ray_sort_tiles(hipStream_t st, const PathStreams& ps, const uint32_t* mPtr, uint32_t nMax, const SortBox& box, uint32_t* H,
-                           uint32_t* perm)
+                           uint32_t* perm, bool largeScene)
 {
     if (!nMax) return;
+    const uint32_t bits = largeScene ? SORT_GBITS_LARGE : SORT_GBITS, bins = 1u << bits, nTiles = bins * SORT_GCOLS / SORT_TILE;
     uint32_t* sums = H + SORT_GBINS * SORT_GCOLS;
     const uint32_t cols = std::min<uint32_t>((nMax + SORT_GTILE - 1u) / SORT_GTILE, SORT_GCOLS);
-    if (cols < SORT_GCOLS) (void)hipMemsetAsync(H, 0, (size_t)SORT_GBINS * SORT_GCOLS * sizeof(uint32_t), st);     // columns no block writes
-    hipLaunchKernelGGL(k_sortg_hist, dim3(cols), dim3(256), 0, st, ps, mPtr, box, H);
-    hipLaunchKernelGGL(k_sort_scan_tiles, dim3(SORT_GSCAN_TILES), dim3(256), 0, st, H, sums);
-    hipLaunchKernelGGL(k_sortg_scan_sums, dim3(1), dim3(1024), 0, st, sums);
-    hipLaunchKernelGGL(k_sortg_scatter, dim3(cols), dim3(256), 0, st, ps, mPtr, box, H, sums, perm);
+    if (cols < SORT_GCOLS) (void)hipMemsetAsync(H, 0, (size_t)bins * SORT_GCOLS * sizeof(uint32_t), st);     // columns no block writes
+    hipLaunchKernelGGL(k_sortg_hist, dim3(cols), dim3(256), 0, st, ps, mPtr, box, H, bits);
+    hipLaunchKernelGGL(k_sort_scan_tiles, dim3(nTiles), dim3(256), 0, st, H, sums);
+    hipLaunchKernelGGL(k_sortg_scan_sums, dim3(1), dim3(1024), 0, st, sums, nTiles);
+    hipLaunchKernelGGL(k_sortg_scatter, dim3(cols), dim3(256), 0, st, ps, mPtr, box, H, sums, perm, bits);
 }
 uint32_t ray_sort_tiles_words() { return SORT_GBINS * SORT_GCOLS + SORT_GSCAN_TILES; }
 

@@ -2221,7 +2221,7 @@ static int trace_rays_device(uint32_t width, uint32_t height)
                     // per-bounce ray sort: the traversal launch below hands its rays out in (octant, Morton cell) order
                     if (!G.sortBins) HIP_OK(hipMalloc(reinterpret_cast<void**>(&G.sortBins), (size_t)ray_sort_tiles_words() * 4));
                     g_timer.begin(&g.stats.ms_sort, G.s0);
-                    launch_ray_sort_tiles(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permE);
+                    launch_ray_sort_tiles(G.s0, ps, G.dCounts + d + 1, n0, sortBox, G.sortBins, G.permE, acc(bTlas)->nWide >= RDX_SORT_AUTO_MIN_WIDE);
                     g_timer.end(G.s0);
                     ps.permS = G.permE; ps.permE = G.permE;
                 }
